@@ -1,0 +1,999 @@
+/*
+ * vamp_oracle.c — CPU ORACLE (TEST INFRASTRUCTURE ONLY; see vamp_oracle.h).
+ *
+ * Restates, function by function, the reference's hot path.  `file:line`
+ * citations are relative to /root/reference/src/impl/vamp/.
+ * Build: gcc -O2 -std=c11 -ffp-contract=off -fno-fast-math (oracle/Makefile).
+ */
+#include "vamp_oracle.h"
+
+#include <math.h>
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------------- */
+/* L0: SIMD value-type semantics, one lane at a time                          */
+/* ------------------------------------------------------------------------- */
+
+static inline uint32_t f2u(float f)
+{
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    return u;
+}
+static inline float u2f(uint32_t u)
+{
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+/* test_zero() is "no lane has its sign bit set" (vector/interface.hh:257-277, avx.hh:385-389);
+ * every collision predicate is `not expr.test_zero()`, i.e. some lane's sign bit is set. */
+static inline int signbit_set(float f) { return (int) (f2u(f) >> 31); }
+/* _mm256_max_ps(a, b): a > b ? a : b (returns b when either is NaN) (avx.hh:435-439) */
+static inline float x86_max(float a, float b) { return a > b ? a : b; }
+/* _mm256_min_ps(a, b): a < b ? a : b */
+static inline float x86_min(float a, float b) { return a < b ? a : b; }
+/* clamp = min(max(v, lower), upper) (avx.hh:429-433) */
+static inline float vclamp(float v, float lo, float hi) { return x86_min(x86_max(v, lo), hi); }
+
+/* vector/avx.hh:455-548 — cephes/sse_mathfun sine, all steps as separate fp32 operations */
+static float vo_sinf(float x)
+{
+    uint32_t sign_bit = f2u(x) & 0x80000000u;
+    x = u2f(f2u(x) & 0x7fffffffu);
+    float y = x * 1.27323954473516f; /* 4/pi */
+    /* _mm256_cvtps_epi32: round to nearest even; out of range -> 0x80000000 */
+    int32_t j;
+    if (!(y < 2147483648.0f))
+        j = INT32_MIN;
+    else
+        j = (int32_t) lrintf(y);
+    j = (int32_t) (((uint32_t) j + 1u) & ~1u);
+    y = (float) j;
+    uint32_t swap_sign = ((uint32_t) j & 4u) << 29;
+    int poly_sin = (((uint32_t) j & 2u) == 0u);
+    sign_bit ^= swap_sign;
+    /* extended precision modular arithmetic: x = ((x - y*DP1) - y*DP2) - y*DP3 */
+    float xmm1 = y * -0.78515625f;
+    float xmm2 = y * -2.4187564849853515625e-4f;
+    float xmm3 = y * -3.77489497744594108e-8f;
+    x = x + xmm1;
+    x = x + xmm2;
+    x = x + xmm3;
+    /* first polynomial (0 <= x <= pi/4) */
+    float z = x * x;
+    float yc = 2.443315711809948E-005f;
+    yc = yc * z;
+    yc = yc + -1.388731625493765E-003f;
+    yc = yc * z;
+    yc = yc + 4.166664568298827E-002f;
+    yc = yc * z;
+    yc = yc * z;
+    float tmp = z * 0.5f;
+    yc = yc - tmp;
+    yc = yc + 1.0f;
+    /* second polynomial */
+    float y2 = -1.9515295891E-4f;
+    y2 = y2 * z;
+    y2 = y2 + 8.3321608736E-3f;
+    y2 = y2 * z;
+    y2 = y2 + -1.6666654611E-1f;
+    y2 = y2 * z;
+    y2 = y2 * x;
+    y2 = y2 + x;
+    /* select: and/andnot with the mask, then add (adds +0.0f to the selected value) */
+    float sel = poly_sin ? (0.0f + y2) : (yc + 0.0f);
+    return u2f(f2u(sel) ^ sign_bit);
+}
+
+/* vector/interface.hh:447-458 — cos through the shifted sine */
+static float vo_cosf(float x)
+{
+    const float PI = 3.14159265359f;
+    const float v_sq = x + (float) (PI / 2.);
+    const float sub = (v_sq >= PI) ? (float) (2 * PI) : 0.0f;
+    const float vsq_sq = v_sq - sub;
+    return vo_sinf(vsq_sq);
+}
+
+float vo_sin(float x) { return vo_sinf(x); }
+float vo_cos(float x) { return vo_cosf(x); }
+
+/* hsum (avx.hh:441-452) over the 8 lanes of one row: ((v4+v0)+(v6+v2)) + ((v5+v1)+(v7+v3)) */
+static float hsum8(const float *v)
+{
+    const float s0 = v[4] + v[0], s1 = v[5] + v[1], s2 = v[6] + v[2], s3 = v[7] + v[3];
+    const float a = s0 + s2, b = s1 + s3;
+    return a + b;
+}
+
+/* l2_norm (interface.hh:397-410): rows are added first (unpack::sum_), then hsum, then exact sqrt */
+float vo_l2_norm(const float *v, size_t dim)
+{
+    float sq[16] = {0};
+    for (size_t i = 0; i < dim && i < 16; ++i) sq[i] = v[i] * v[i];
+    float row[8];
+    if (dim > 8)
+        for (int k = 0; k < 8; ++k) row[k] = sq[k] + sq[8 + k];
+    else
+        memcpy(row, sq, sizeof(row));
+    return sqrtf(hsum8(row));
+}
+
+/* ------------------------------------------------------------------------- */
+/* L1a: environment                                                           */
+/* ------------------------------------------------------------------------- */
+
+typedef struct
+{
+    float x, y, z, r, min_distance;
+} vo_sphere;
+typedef struct
+{
+    float p[15];
+    float min_distance;
+} vo_cuboid;
+typedef struct
+{
+    float x1, y1, z1, xv, yv, zv, r, rdv, min_distance;
+} vo_capsule;
+
+typedef struct
+{
+    uint32_t nlog2, n_tests, n_leaves, n_aff;
+    float *tests;
+    uint32_t *aff_starts;
+    float *aabbs;
+    float *aff[3];
+    float aabb_top[6];
+    float r_min, r_max, r_point;
+} vo_capt;
+
+struct vo_env
+{
+    vo_sphere *spheres;
+    size_t n_spheres;
+    vo_capsule *capsules;
+    size_t n_capsules;
+    vo_capsule *z_capsules;
+    size_t n_z_capsules;
+    vo_cuboid *cuboids;
+    size_t n_cuboids;
+    vo_cuboid *z_cuboids;
+    size_t n_z_cuboids;
+    vo_capt *capts;
+    size_t n_capts;
+};
+
+vo_env *vo_env_create(void) { return (vo_env *) calloc(1, sizeof(vo_env)); }
+
+static void capt_free(vo_capt *c)
+{
+    free(c->tests);
+    free(c->aff_starts);
+    free(c->aabbs);
+    free(c->aff[0]);
+    free(c->aff[1]);
+    free(c->aff[2]);
+}
+
+void vo_env_destroy(vo_env *e)
+{
+    if (!e) return;
+    free(e->spheres);
+    free(e->capsules);
+    free(e->z_capsules);
+    free(e->cuboids);
+    free(e->z_cuboids);
+    for (size_t i = 0; i < e->n_capts; ++i) capt_free(&e->capts[i]);
+    free(e->capts);
+    free(e);
+}
+
+static float dot3(float ax, float ay, float az, float bx, float by, float bz)
+{
+    return (ax * bx) + (ay * by) + (az * bz); /* collision/math.hh:16-26 */
+}
+/* scalar clamp<float> (collision/math.hh:47-51): max(min(v, upper), lower) */
+static float sclamp(float v, float lo, float hi) { return fmaxf(fminf(v, hi), lo); }
+
+#define SORT_BY_MIN_DISTANCE(T, name)                                     \
+    static int name(const void *a, const void *b)                         \
+    {                                                                     \
+        const float da = ((const T *) a)->min_distance;                   \
+        const float db = ((const T *) b)->min_distance;                   \
+        return (da < db) ? -1 : (da > db) ? 1 : 0;                        \
+    }
+SORT_BY_MIN_DISTANCE(vo_sphere, cmp_sphere)
+SORT_BY_MIN_DISTANCE(vo_cuboid, cmp_cuboid)
+SORT_BY_MIN_DISTANCE(vo_capsule, cmp_capsule)
+
+/* collision/shapes.hh:236-239 + environment.cc:113-119 (push_back; sort()) */
+void vo_env_add_sphere(vo_env *e, float x, float y, float z, float r)
+{
+    e->spheres = (vo_sphere *) realloc(e->spheres, (e->n_spheres + 1) * sizeof(vo_sphere));
+    vo_sphere s = {x, y, z, r, sqrtf(x * x + y * y + z * z) - r};
+    e->spheres[e->n_spheres++] = s;
+    qsort(e->spheres, e->n_spheres, sizeof(vo_sphere), cmp_sphere);
+}
+
+/* collision/shapes.hh:52-67 */
+static float cuboid_min_distance(const float *p)
+{
+    const float x = p[0], y = p[1], z = p[2];
+    const float d1 = dot3(-x, -y, -z, p[3], p[4], p[5]);
+    const float d2 = dot3(-x, -y, -z, p[6], p[7], p[8]);
+    const float d3 = dot3(-x, -y, -z, p[9], p[10], p[11]);
+    const float v1 = sclamp(d1, -p[12], p[12]);
+    const float v2 = sclamp(d2, -p[13], p[13]);
+    const float v3 = sclamp(d3, -p[14], p[14]);
+    const float xn = x + p[3] * v1 + p[6] * v2 + p[9] * v3;
+    const float yn = y + p[4] * v1 + p[7] * v2 + p[10] * v3;
+    const float zn = z + p[5] * v1 + p[8] * v2 + p[11] * v3;
+    return sqrtf(xn * xn + yn * yn + zn * zn);
+}
+
+/* environment.cc:120-133: z-aligned iff axis_3_z == 1 */
+void vo_env_add_cuboid(vo_env *e, const float *p)
+{
+    vo_cuboid c;
+    memcpy(c.p, p, sizeof(c.p));
+    c.min_distance = cuboid_min_distance(p);
+    if (p[11] == 1.0f)
+    {
+        e->z_cuboids = (vo_cuboid *) realloc(e->z_cuboids, (e->n_z_cuboids + 1) * sizeof(vo_cuboid));
+        e->z_cuboids[e->n_z_cuboids++] = c;
+        qsort(e->z_cuboids, e->n_z_cuboids, sizeof(vo_cuboid), cmp_cuboid);
+    }
+    else
+    {
+        e->cuboids = (vo_cuboid *) realloc(e->cuboids, (e->n_cuboids + 1) * sizeof(vo_cuboid));
+        e->cuboids[e->n_cuboids++] = c;
+        qsort(e->cuboids, e->n_cuboids, sizeof(vo_cuboid), cmp_cuboid);
+    }
+}
+
+/* collision/shapes.hh:165-189 */
+static float capsule_min_distance(const vo_capsule *c)
+{
+    const float dot = sclamp(dot3(-c->x1, -c->y1, -c->z1, c->xv, c->yv, c->zv) * c->rdv, 0.F, 1.F);
+    const float xp = c->x1 + c->xv * dot, yp = c->y1 + c->yv * dot, zp = c->z1 + c->zv * dot;
+    float xo = -xp, yo = -yp, zo = -zp;
+    const float ol = sqrtf(dot3(xo, yo, zo, xo, yo, zo));
+    xo = xo / ol;
+    yo = yo / ol;
+    zo = zo / ol;
+    const float ro = sclamp(ol, 0.F, c->r);
+    const float xn = xp + ro * xo, yn = yp + ro * yo, zn = zp + ro * zo;
+    return sqrtf(xn * xn + yn * yn + zn * zn);
+}
+
+/* environment.cc:134-147: z-aligned iff xv == 0 and yv == 0 */
+void vo_env_add_capsule(vo_env *e, const float *p)
+{
+    vo_capsule c = {p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7], 0.F};
+    c.min_distance = capsule_min_distance(&c);
+    if (c.xv == 0.F && c.yv == 0.F)
+    {
+        e->z_capsules = (vo_capsule *) realloc(e->z_capsules, (e->n_z_capsules + 1) * sizeof(vo_capsule));
+        e->z_capsules[e->n_z_capsules++] = c;
+        qsort(e->z_capsules, e->n_z_capsules, sizeof(vo_capsule), cmp_capsule);
+    }
+    else
+    {
+        e->capsules = (vo_capsule *) realloc(e->capsules, (e->n_capsules + 1) * sizeof(vo_capsule));
+        e->capsules[e->n_capsules++] = c;
+        qsort(e->capsules, e->n_capsules, sizeof(vo_capsule), cmp_capsule);
+    }
+}
+
+void vo_env_counts(const vo_env *e, size_t counts[6])
+{
+    counts[0] = e->n_spheres;
+    counts[1] = e->n_capsules;
+    counts[2] = e->n_z_capsules;
+    counts[3] = e->n_cuboids;
+    counts[4] = e->n_z_cuboids;
+    counts[5] = e->n_capts;
+}
+
+size_t vo_env_get_spheres(const vo_env *e, float *out)
+{
+    for (size_t i = 0; i < e->n_spheres; ++i) memcpy(out + 5 * i, &e->spheres[i], 5 * sizeof(float));
+    return e->n_spheres;
+}
+size_t vo_env_get_cuboids(const vo_env *e, int z, float *out)
+{
+    const vo_cuboid *c = z ? e->z_cuboids : e->cuboids;
+    const size_t n = z ? e->n_z_cuboids : e->n_cuboids;
+    for (size_t i = 0; i < n; ++i) memcpy(out + 16 * i, &c[i], 16 * sizeof(float));
+    return n;
+}
+size_t vo_env_get_capsules(const vo_env *e, int z, float *out)
+{
+    const vo_capsule *c = z ? e->z_capsules : e->capsules;
+    const size_t n = z ? e->n_z_capsules : e->n_capsules;
+    for (size_t i = 0; i < n; ++i) memcpy(out + 9 * i, &c[i], 9 * sizeof(float));
+    return n;
+}
+
+/* ------------------------------------------------------------------------- */
+/* CAPT build (collision/capt.hh:106-369), bug-for-bug                        */
+/* ------------------------------------------------------------------------- */
+
+typedef struct
+{
+    float lower[3], upper[3];
+} vo_volume;
+
+/* capt.hh:30-37 */
+static void vol_extend(vo_volume *v, const float *p)
+{
+    for (int k = 0; k < 3; ++k)
+    {
+        v->lower[k] = fminf(v->lower[k], p[k]);
+        v->upper[k] = fmaxf(v->upper[k], p[k]);
+    }
+}
+/* capt.hh:39-46 */
+static int vol_contained_by_internal_ball(const vo_volume *v, const float *p, float r)
+{
+    const float d0 = fmaxf(p[0] - v->lower[0], v->upper[0] - p[0]);
+    const float d1 = fmaxf(p[1] - v->lower[1], v->upper[1] - p[1]);
+    const float d2 = fmaxf(p[2] - v->lower[2], v->upper[2] - p[2]);
+    return (d0 * d0 + d1 * d1 + d2 * d2) <= r;
+}
+/* std::clamp(v, lo, hi) */
+static float stdclamp(float v, float lo, float hi) { return (v < lo) ? lo : (hi < v) ? hi : v; }
+/* capt.hh:48-55 */
+static float vol_distsq_to(const vo_volume *v, const float *p)
+{
+    const float d0 = p[0] - stdclamp(p[0], v->lower[0], v->upper[0]);
+    const float d1 = p[1] - stdclamp(p[1], v->lower[1], v->upper[1]);
+    const float d2 = p[2] - stdclamp(p[2], v->lower[2], v->upper[2]);
+    return d0 * d0 + d1 * d1 + d2 * d2;
+}
+
+typedef struct
+{
+    const float *points; /* [n][3] padded */
+    uint32_t *argsort;
+    vo_capt *c;
+    float max_aff_l2, min_aff_l2;
+    /* growing outputs */
+    size_t aff_cap, n_leaves_done;
+} capt_builder;
+
+static const float *g_sort_points;
+static int g_sort_k;
+static int cmp_argsort(const void *a, const void *b)
+{
+    const float fa = g_sort_points[3 * (size_t) (*(const uint32_t *) a) + g_sort_k];
+    const float fb = g_sort_points[3 * (size_t) (*(const uint32_t *) b) + g_sort_k];
+    if (fa < fb) return -1;
+    if (fb < fa) return 1;
+    /* the reference's pdqsort_branchless leaves the order of equal keys unspecified;
+     * index order is used here (fixtures avoid duplicate coordinates) */
+    const uint32_t ia = *(const uint32_t *) a, ib = *(const uint32_t *) b;
+    return (ia < ib) ? -1 : (ia > ib);
+}
+
+/* capt.hh:106-123 */
+static float median_partition(capt_builder *b, uint32_t begin, uint32_t end, int k)
+{
+    g_sort_points = b->points;
+    g_sort_k = k;
+    qsort(b->argsort + begin, end - begin, sizeof(uint32_t), cmp_argsort);
+    const uint32_t middle = begin + (end - begin) / 2;
+    const float lo = b->points[3 * (size_t) b->argsort[middle - 1] + k];
+    const float hi = b->points[3 * (size_t) b->argsort[middle] + k];
+    return (float) ((double) (lo + hi) / 2.0);
+}
+
+static void aff_push(capt_builder *b, const float *xs, const float *ys, const float *zs)
+{
+    vo_capt *c = b->c;
+    if (c->n_aff == b->aff_cap)
+    {
+        b->aff_cap = b->aff_cap ? b->aff_cap * 2 : 1024;
+        for (int k = 0; k < 3; ++k) c->aff[k] = (float *) realloc(c->aff[k], b->aff_cap * VO_RAKE * sizeof(float));
+    }
+    memcpy(c->aff[0] + (size_t) c->n_aff * VO_RAKE, xs, VO_RAKE * sizeof(float));
+    memcpy(c->aff[1] + (size_t) c->n_aff * VO_RAKE, ys, VO_RAKE * sizeof(float));
+    memcpy(c->aff[2] + (size_t) c->n_aff * VO_RAKE, zs, VO_RAKE * sizeof(float));
+    c->n_aff++;
+}
+
+/* capt.hh:125-290; `afford` is owned by the callee (freed here) */
+static void subdivide(capt_builder *b, uint32_t points_begin, uint32_t how_many, uint32_t i, uint32_t *afford,
+                      uint32_t n_afford, vo_volume volume, int d)
+{
+    vo_capt *c = b->c;
+    const float *points = b->points;
+    uint32_t *argsort = b->argsort;
+    if (how_many == 1)
+    {
+        const float *rep = points + 3 * (size_t) argsort[points_begin];
+        vo_volume aabb;
+        memcpy(aabb.lower, rep, 12);
+        memcpy(aabb.upper, rep, 12);
+        if (isfinite(rep[0]))
+        {
+            vo_volume top;
+            memcpy(top.lower, c->aabb_top, 12);
+            memcpy(top.upper, c->aabb_top + 3, 12);
+            vol_extend(&top, rep);
+            memcpy(c->aabb_top, top.lower, 12);
+            memcpy(c->aabb_top + 3, top.upper, 12);
+
+            float xs[VO_RAKE] = {rep[0]}, ys[VO_RAKE] = {rep[1]}, zs[VO_RAKE] = {rep[2]};
+            int j = 1;
+            if (!vol_contained_by_internal_ball(&volume, rep, b->min_aff_l2))
+            {
+                for (uint32_t t = 0; t < n_afford; ++t)
+                {
+                    const float *p = points + 3 * (size_t) afford[t];
+                    if (vol_distsq_to(&volume, p) <= b->max_aff_l2)
+                    {
+                        vol_extend(&aabb, p);
+                        xs[j] = p[0];
+                        ys[j] = p[1];
+                        zs[j] = p[2];
+                        j++;
+                        if (j == VO_RAKE)
+                        {
+                            aff_push(b, xs, ys, zs);
+                            j = 0;
+                        }
+                    }
+                }
+            }
+            if (j > 0)
+            {
+                for (int jj = j; jj < VO_RAKE; ++jj) xs[jj] = ys[jj] = zs[jj] = INFINITY;
+                aff_push(b, xs, ys, zs);
+            }
+        }
+        memcpy(c->aabbs + 6 * b->n_leaves_done, aabb.lower, 12);
+        memcpy(c->aabbs + 6 * b->n_leaves_done + 3, aabb.upper, 12);
+        b->n_leaves_done++;
+        c->aff_starts[b->n_leaves_done] = c->n_aff;
+        free(afford);
+        return;
+    }
+
+    const float test = median_partition(b, points_begin, points_begin + how_many, d);
+    c->tests[i] = test;
+    const uint32_t next_width = how_many / 2;
+    vo_volume lo_vol = volume, hi_vol = volume;
+    lo_vol.upper[d] = test;
+    hi_vol.lower[d] = test;
+
+    const float r_max = c->r_max;
+    uint32_t *hi_afford = afford; /* moved */
+    uint32_t *lo_afford = (uint32_t *) malloc((n_afford + how_many + 1) * sizeof(uint32_t));
+    uint32_t hi_len = 0, lo_len = 0;
+    for (uint32_t t = 0; t < n_afford; ++t)
+    {
+        const uint32_t idx = hi_afford[t];
+        const float v = points[3 * (size_t) idx + d];
+        if (v <= test + r_max) lo_afford[lo_len++] = idx;
+        if (v >= test - r_max) hi_afford[hi_len++] = idx;
+    }
+    uint32_t new_hi = points_begin;
+    uint32_t new_lo = points_begin + next_width;
+    while (new_hi < points_begin + next_width && points[3 * (size_t) argsort[new_hi] + d] >= test - r_max &&
+           isfinite(points[3 * (size_t) argsort[new_hi] + d]))
+        ++new_hi;
+    while (new_lo < points_begin + how_many && points[3 * (size_t) argsort[new_lo] + d] <= test + r_max &&
+           isfinite(points[3 * (size_t) argsort[new_lo] + d]))
+        ++new_lo;
+    const uint32_t num_new_hi = new_hi - points_begin;
+    const uint32_t num_new_lo = new_lo - (points_begin + next_width);
+    hi_afford = (uint32_t *) realloc(hi_afford, (hi_len + num_new_hi + 1) * sizeof(uint32_t));
+    memcpy(hi_afford + hi_len, argsort + points_begin, num_new_hi * sizeof(uint32_t));
+    memcpy(lo_afford + lo_len, argsort + points_begin + next_width, num_new_lo * sizeof(uint32_t));
+
+    const int next_d = (d + 1) % 3;
+    subdivide(b, points_begin, next_width, 2 * i + 1, lo_afford, lo_len + num_new_lo, lo_vol, next_d);
+    subdivide(b, points_begin + next_width, next_width, 2 * i + 2, hi_afford, hi_len + num_new_hi, hi_vol, next_d);
+}
+
+/* capt.hh:296-369 */
+int vo_env_add_capt(vo_env *e, const float *pts, size_t n, float r_min, float r_max, float r_point)
+{
+    if (n < 2) return -1;
+    vo_capt c;
+    memset(&c, 0, sizeof(c));
+    c.r_min = r_min;
+    c.r_max = r_max;
+    c.r_point = r_point;
+    const float max_aff_l1 = r_max + r_point;
+    capt_builder b;
+    memset(&b, 0, sizeof(b));
+    b.max_aff_l2 = max_aff_l1 * max_aff_l1;
+    b.min_aff_l2 = (r_min + r_point) * (r_min + r_point);
+    while (((size_t) 1u << c.nlog2) < n) c.nlog2++;
+    const size_t pow2 = (size_t) 1u << c.nlog2;
+    float *points2 = (float *) malloc(pow2 * 3 * sizeof(float));
+    memcpy(points2, pts, n * 3 * sizeof(float));
+    for (size_t i = n * 3; i < pow2 * 3; ++i) points2[i] = INFINITY;
+    for (int k = 0; k < 3; ++k)
+    {
+        c.aabb_top[k] = INFINITY;
+        c.aabb_top[3 + k] = -INFINITY;
+    }
+    c.n_tests = (uint32_t) pow2 - 1;
+    c.n_leaves = (uint32_t) pow2;
+    c.tests = (float *) malloc((pow2) * sizeof(float));
+    for (size_t i = 0; i < pow2; ++i) c.tests[i] = NAN;
+    c.aff_starts = (uint32_t *) calloc(pow2 + 1, sizeof(uint32_t));
+    c.aabbs = (float *) malloc(pow2 * 6 * sizeof(float));
+    uint32_t *argsort = (uint32_t *) malloc(pow2 * sizeof(uint32_t));
+    for (size_t i = 0; i < pow2; ++i) argsort[i] = (uint32_t) i;
+    b.points = points2;
+    b.argsort = argsort;
+    b.c = &c;
+    vo_volume all;
+    for (int k = 0; k < 3; ++k)
+    {
+        all.lower[k] = -INFINITY;
+        all.upper[k] = INFINITY;
+    }
+    subdivide(&b, 0u, (uint32_t) pow2, 0u, (uint32_t *) malloc(sizeof(uint32_t)), 0u, all, 0);
+    free(argsort);
+    free(points2);
+    e->capts = (vo_capt *) realloc(e->capts, (e->n_capts + 1) * sizeof(vo_capt));
+    e->capts[e->n_capts++] = c;
+    return 0;
+}
+
+int vo_env_capt_view(const vo_env *e, size_t index, vo_capt_view *out)
+{
+    if (index >= e->n_capts) return -1;
+    const vo_capt *c = &e->capts[index];
+    out->nlog2 = c->nlog2;
+    out->n_tests = c->n_tests;
+    out->n_leaves = c->n_leaves;
+    out->n_aff_vectors = c->n_aff;
+    out->tests = c->tests;
+    out->aff_starts = c->aff_starts;
+    out->aabbs = c->aabbs;
+    out->aff_x = c->aff[0];
+    out->aff_y = c->aff[1];
+    out->aff_z = c->aff[2];
+    memcpy(out->aabb_top, c->aabb_top, sizeof(out->aabb_top));
+    out->r_min = c->r_min;
+    out->r_max = c->r_max;
+    out->r_point = c->r_point;
+    return 0;
+}
+
+/* CAPT::collides (capt.hh:374-415) */
+static int capt_collides_scalar(const vo_capt *c, const float ctr[3], float r)
+{
+    vo_volume top;
+    memcpy(top.lower, c->aabb_top, 12);
+    memcpy(top.upper, c->aabb_top + 3, 12);
+    if (vol_distsq_to(&top, ctr) > r * r) return 0;
+    size_t test_idx = 0;
+    for (uint32_t i = 0, k = 0; i < c->nlog2; ++i)
+    {
+        test_idx = 2 * test_idx + 1 + (ctr[k] >= c->tests[test_idx]);
+        k = (k + 1) % 3;
+    }
+    const size_t z = test_idx - c->n_tests;
+    r += c->r_point;
+    const float radius_sq = r * r;
+    vo_volume bb;
+    memcpy(bb.lower, c->aabbs + 6 * z, 12);
+    memcpy(bb.upper, c->aabbs + 6 * z + 3, 12);
+    if (vol_distsq_to(&bb, ctr) > radius_sq) return 0;
+    for (uint32_t i = c->aff_starts[z]; i < c->aff_starts[z + 1]; ++i)
+        for (int l = 0; l < VO_RAKE; ++l)
+        {
+            const float xs = c->aff[0][(size_t) i * VO_RAKE + l] - ctr[0];
+            const float ys = c->aff[1][(size_t) i * VO_RAKE + l] - ctr[1];
+            const float zs = c->aff[2][(size_t) i * VO_RAKE + l] - ctr[2];
+            if (dot3(xs, ys, zs, xs, ys, zs) <= radius_sq) return 1;
+        }
+    return 0;
+}
+
+/* CAPT::collides_simd (capt.hh:428-512) over `lanes` lanes; result = any lane collides */
+static int capt_collides_simd(const vo_capt *c, const float *cx, const float *cy, const float *cz, const float *radii,
+                              int lanes)
+{
+    const float *ctr[3] = {cx, cy, cz};
+    int inbounds[VO_RAKE];
+    int any = 0;
+    for (int l = 0; l < lanes; ++l)
+    {
+        int in = 1;
+        for (int k = 0; k < 3; ++k)
+            in = in && (ctr[k][l] + radii[l] >= c->aabb_top[k]) && (ctr[k][l] - radii[l] <= c->aabb_top[3 + k]);
+        inbounds[l] = in;
+        any |= in;
+    }
+    if (!any) return 0;
+
+    uint32_t zs[VO_RAKE];
+    float rc_sq[VO_RAKE];
+    any = 0;
+    for (int l = 0; l < lanes; ++l)
+    {
+        uint32_t idx = (uint32_t) (ctr[0][l] >= c->tests[0]) + 1u;
+        for (uint32_t i = 1, k = 1; i < c->nlog2; ++i)
+        {
+            idx = (idx << 1) + (uint32_t) (ctr[k][l] >= c->tests[idx]) + 1u;
+            k = (k + 1) % 3;
+        }
+        zs[l] = idx - c->n_tests;
+        const float rr = radii[l] + c->r_point;
+        rc_sq[l] = rr * rr;
+        const float *bb = c->aabbs + 6 * (size_t) zs[l];
+        const float d0 = ctr[0][l] - vclamp(ctr[0][l], bb[0], bb[3]);
+        const float d1 = ctr[1][l] - vclamp(ctr[1][l], bb[1], bb[4]);
+        const float d2 = ctr[2][l] - vclamp(ctr[2][l], bb[2], bb[5]);
+        const float distsq = d0 * d0 + d1 * d1 + d2 * d2;
+        inbounds[l] = inbounds[l] && (distsq <= rc_sq[l]);
+        any |= inbounds[l];
+    }
+    if (!any) return 0;
+
+    for (int l = 0; l < lanes; ++l)
+    {
+        const uint32_t start = c->aff_starts[zs[l]];
+        const uint32_t end = inbounds[l] ? c->aff_starts[zs[l] + 1] : 0u;
+        for (uint32_t i = start; i < end; ++i)
+            for (int p = 0; p < VO_RAKE; ++p)
+            {
+                const float xs = c->aff[0][(size_t) i * VO_RAKE + p] - ctr[0][l];
+                const float ys = c->aff[1][(size_t) i * VO_RAKE + p] - ctr[1][l];
+                const float z_ = c->aff[2][(size_t) i * VO_RAKE + p] - ctr[2][l];
+                if (dot3(xs, ys, z_, xs, ys, z_) <= rc_sq[l]) return 1;
+            }
+    }
+    return 0;
+}
+
+int vo_capt_collides(const vo_env *e, size_t index, const float c[3], float r)
+{
+    return capt_collides_scalar(&e->capts[index], c, r);
+}
+int vo_capt_collides_simd(const vo_env *e, size_t index, const float *cx, const float *cy, const float *cz,
+                          const float *r, int lanes)
+{
+    return capt_collides_simd(&e->capts[index], cx, cy, cz, r, lanes);
+}
+
+/* ------------------------------------------------------------------------- */
+/* collision primitives (collision/sphere_*.hh), one lane                     */
+/* ------------------------------------------------------------------------- */
+
+/* collision/math.hh:28-42 */
+static inline float sql2_3(float ax, float ay, float az, float bx, float by, float bz)
+{
+    const float xs = ax - bx, ys = ay - by, zs = az - bz;
+    return dot3(xs, ys, zs, xs, ys, zs);
+}
+/* collision/sphere_sphere.hh:9-23 */
+static inline float sphere_sphere_sql2(float ax, float ay, float az, float ar, float bx, float by, float bz, float br)
+{
+    const float sum = sql2_3(ax, ay, az, bx, by, bz);
+    const float rs = ar + br;
+    return sum - rs * rs;
+}
+/* collision/sphere_cuboid.hh:8-27 */
+static inline float sphere_cuboid(const float *c, float x, float y, float z, float rsq)
+{
+    const float xs = x - c[0], ys = y - c[1], zs = z - c[2];
+    const float a1 = x86_max(fabsf(dot3(c[3], c[4], c[5], xs, ys, zs)) - c[12], 0.f);
+    const float a2 = x86_max(fabsf(dot3(c[6], c[7], c[8], xs, ys, zs)) - c[13], 0.f);
+    const float a3 = x86_max(fabsf(dot3(c[9], c[10], c[11], xs, ys, zs)) - c[14], 0.f);
+    return dot3(a1, a2, a3, a1, a2, a3) - rsq;
+}
+/* collision/sphere_cuboid.hh:35-52 */
+static inline float sphere_z_aligned_cuboid(const float *c, float x, float y, float z, float rsq)
+{
+    const float xs = x - c[0], ys = y - c[1], zs = z - c[2];
+    const float a1 = x86_max(fabsf((c[3] * xs) + (c[4] * ys)) - c[12], 0.f);
+    const float a2 = x86_max(fabsf((c[6] * xs) + (c[7] * ys)) - c[13], 0.f);
+    const float a3 = x86_max(fabsf(zs) - c[14], 0.f);
+    return dot3(a1, a2, a3, a1, a2, a3) - rsq;
+}
+/* collision/sphere_capsule.hh:8-23 */
+static inline float sphere_capsule(const vo_capsule *c, float x, float y, float z, float r)
+{
+    const float dot = dot3(x - c->x1, y - c->y1, z - c->z1, c->xv, c->yv, c->zv);
+    const float cdf = vclamp(dot * c->rdv, 0.F, 1.F);
+    const float sum = sql2_3(x, y, z, c->x1 + c->xv * cdf, c->y1 + c->yv * cdf, c->z1 + c->zv * cdf);
+    const float rs = r + c->r;
+    return sum - rs * rs;
+}
+/* collision/sphere_capsule.hh:31-45 */
+static inline float sphere_z_aligned_capsule(const vo_capsule *c, float x, float y, float z, float r)
+{
+    const float dot = (z - c->z1) * c->zv;
+    const float cdf = vclamp(dot * c->rdv, 0.F, 1.F);
+    const float sum = sql2_3(x, y, z, c->x1, c->y1, c->z1 + c->zv * cdf);
+    const float rs = r + c->r;
+    return sum - rs * rs;
+}
+
+/* ------------------------------------------------------------------------- */
+/* sphere_environment_in_collision (collision/validity.hh:47-158) on a rake   */
+/* ------------------------------------------------------------------------- */
+
+static int sphere_environment_in_collision(const vo_env *e, const float *sx, const float *sy, const float *sz,
+                                           float sr, int lanes)
+{
+    float max_extent[VO_RAKE];
+    /* validity.hh:59 — the reference's approximate sqrt is replaced by the correctly rounded one (header note) */
+    for (int l = 0; l < lanes; ++l) max_extent[l] = sqrtf(dot3(sx[l], sy[l], sz[l], sx[l], sy[l], sz[l])) + sr;
+
+#define LIST_LOOP(COUNT, MIN_DISTANCE, TEST)                                  \
+    for (size_t i = 0; i < (COUNT); ++i)                                     \
+    {                                                                        \
+        int any_neg = 0;                                                     \
+        for (int l = 0; l < lanes; ++l) any_neg |= signbit_set((MIN_DISTANCE) - max_extent[l]); \
+        if (!any_neg) break; /* diff.test_zero() */                          \
+        for (int l = 0; l < lanes; ++l)                                      \
+            if (signbit_set(TEST)) return 1;                                 \
+    }
+
+    LIST_LOOP(e->n_spheres, e->spheres[i].min_distance,
+              sphere_sphere_sql2(e->spheres[i].x, e->spheres[i].y, e->spheres[i].z, e->spheres[i].r, sx[l], sy[l],
+                                 sz[l], sr))
+    LIST_LOOP(e->n_capsules, e->capsules[i].min_distance, sphere_capsule(&e->capsules[i], sx[l], sy[l], sz[l], sr))
+    LIST_LOOP(e->n_z_capsules, e->z_capsules[i].min_distance,
+              sphere_z_aligned_capsule(&e->z_capsules[i], sx[l], sy[l], sz[l], sr))
+    const float rsq = sr * sr;
+    LIST_LOOP(e->n_cuboids, e->cuboids[i].min_distance, sphere_cuboid(e->cuboids[i].p, sx[l], sy[l], sz[l], rsq))
+    LIST_LOOP(e->n_z_cuboids, e->z_cuboids[i].min_distance,
+              sphere_z_aligned_cuboid(e->z_cuboids[i].p, sx[l], sy[l], sz[l], rsq))
+#undef LIST_LOOP
+    /* heightfields: out of scope */
+    float radii[VO_RAKE];
+    for (int l = 0; l < lanes; ++l) radii[l] = sr;
+    for (size_t i = 0; i < e->n_capts; ++i)
+        if (capt_collides_simd(&e->capts[i], sx, sy, sz, radii, lanes)) return 1;
+    return 0;
+}
+
+/* ------------------------------------------------------------------------- */
+/* L1b: robots (generated FK + tables)                                        */
+/* ------------------------------------------------------------------------- */
+
+typedef struct
+{
+    uint16_t bound, n_fine, fine_offset;
+} vo_env_group;
+typedef struct
+{
+    uint16_t bound_a, bound_b, n_pairs;
+    uint32_t pair_offset;
+} vo_self_group;
+typedef struct
+{
+    const char *name;
+    size_t dimension, n_spheres, n_total, resolution;
+    float min_radius, max_radius;
+    void (*fk_all)(const float *q, float *c);
+    void (*fk_fine)(const float *q, float *c);
+    const float *radii;
+    const vo_env_group *env_groups;
+    size_t n_env_groups;
+    const uint16_t *env_fine;
+    const vo_self_group *self_groups;
+    size_t n_self_groups;
+    const uint16_t (*self_pairs)[2];
+    const float *lower, *span, *descale;
+} vo_robot;
+
+#include "gen/robots_gen.inc"
+
+int vo_robot_id(const char *name)
+{
+    for (int i = 0; i < VO_N_ROBOTS; ++i)
+        if (strcmp(vo_robots[i].name, name) == 0) return i;
+    return -1;
+}
+size_t vo_robot_dimension(int r) { return vo_robots[r].dimension; }
+size_t vo_robot_n_spheres(int r) { return vo_robots[r].n_spheres; }
+size_t vo_robot_n_total_spheres(int r) { return vo_robots[r].n_total; }
+size_t vo_robot_resolution(int r) { return vo_robots[r].resolution; }
+void vo_robot_bounds(int r, float *lower, float *span)
+{
+    memcpy(lower, vo_robots[r].lower, vo_robots[r].dimension * sizeof(float));
+    memcpy(span, vo_robots[r].span, vo_robots[r].dimension * sizeof(float));
+}
+
+void vo_fk(int robot, const float *q, float *out)
+{
+    const vo_robot *R = &vo_robots[robot];
+    float c[3 * 256];
+    R->fk_fine(q, c);
+    for (size_t s = 0; s < R->n_spheres; ++s)
+    {
+        out[4 * s + 0] = c[3 * s + 0];
+        out[4 * s + 1] = c[3 * s + 1];
+        out[4 * s + 2] = c[3 * s + 2];
+        out[4 * s + 3] = R->radii[s];
+    }
+}
+void vo_fk_all(int robot, const float *q, float *out)
+{
+    const vo_robot *R = &vo_robots[robot];
+    float c[3 * 256];
+    R->fk_all(q, c);
+    for (size_t s = 0; s < R->n_total; ++s)
+    {
+        out[4 * s + 0] = c[3 * s + 0];
+        out[4 * s + 1] = c[3 * s + 1];
+        out[4 * s + 2] = c[3 * s + 2];
+        out[4 * s + 3] = R->radii[s];
+    }
+}
+
+/* Robot::fkcc<rake> (robots/panda.hh:5226-10262): block[dim][VO_RAKE], first `lanes` lanes used.
+ * lanes = 1 is the same computation for a rake whose 8 lanes hold one replicated configuration. */
+static int fkcc_lanes(int robot, const vo_env *e, const float *block, const int lanes)
+{
+    const vo_robot *R = &vo_robots[robot];
+    /* FK of every lane; centres stored [sphere][xyz][lane] */
+    static _Thread_local float C[256][3][VO_RAKE];
+    for (int l = 0; l < lanes; ++l)
+    {
+        float q[16], c[3 * 256];
+        for (size_t j = 0; j < R->dimension; ++j) q[j] = block[j * VO_RAKE + l];
+        R->fk_all(q, c);
+        for (size_t s = 0; s < R->n_total; ++s)
+            for (int k = 0; k < 3; ++k) C[s][k][l] = c[3 * s + k];
+    }
+#define ENV_HIT(S) sphere_environment_in_collision(e, C[S][0], C[S][1], C[S][2], R->radii[S], lanes)
+    for (size_t g = 0; g < R->n_env_groups; ++g)
+    {
+        const vo_env_group *G = &R->env_groups[g];
+        if (ENV_HIT(G->bound))
+            for (size_t f = 0; f < G->n_fine; ++f)
+            {
+                const unsigned s = R->env_fine[G->fine_offset + f];
+                if (ENV_HIT(s)) return 0;
+            }
+    }
+#undef ENV_HIT
+    /* sphere_sphere_self_collision (collision/validity.hh:23-44) */
+#define SELF_HIT(A, B, RES)                                                                               \
+    do                                                                                                    \
+    {                                                                                                     \
+        (RES) = 0;                                                                                        \
+        for (int l = 0; l < lanes; ++l)                                                                   \
+            (RES) |= signbit_set(sphere_sphere_sql2(C[A][0][l], C[A][1][l], C[A][2][l], R->radii[A],     \
+                                                    C[B][0][l], C[B][1][l], C[B][2][l], R->radii[B]));   \
+    } while (0)
+    for (size_t g = 0; g < R->n_self_groups; ++g)
+    {
+        const vo_self_group *G = &R->self_groups[g];
+        int hit;
+        SELF_HIT(G->bound_a, G->bound_b, hit);
+        if (!hit) continue;
+        for (size_t p = 0; p < G->n_pairs; ++p)
+        {
+            const unsigned a = R->self_pairs[G->pair_offset + p][0], b = R->self_pairs[G->pair_offset + p][1];
+            SELF_HIT(a, b, hit);
+            if (hit) return 0;
+        }
+    }
+#undef SELF_HIT
+    return 1;
+}
+
+int vo_fkcc_rake(int robot, const vo_env *e, const float *block) { return fkcc_lanes(robot, e, block, VO_RAKE); }
+
+/* ------------------------------------------------------------------------- */
+/* L2: the rake (planning/validate.hh:24-77)                                  */
+/* ------------------------------------------------------------------------- */
+
+static int validate_vector(int robot, const vo_env *e, const float *start, const float *vector, float distance,
+                           size_t resolution, int lanes)
+{
+    const vo_robot *R = &vo_robots[robot];
+    const size_t dim = R->dimension;
+    float block[16 * VO_RAKE];
+    /* validate.hh:31-39: block[i] = start[i] + vector[i] * percents, percents[k] = (k+1)/8 */
+    for (size_t i = 0; i < dim; ++i)
+        for (int k = 0; k < VO_RAKE; ++k)
+        {
+            const float percent = (float) (k + 1) / (float) VO_RAKE;
+            block[i * VO_RAKE + k] = start[i] + (vector[i] * percent);
+        }
+    /* validate.hh:41 */
+    const size_t n = (size_t) fmaxf(ceilf(distance / (float) VO_RAKE * (float) resolution), 1.F);
+    int valid = fkcc_lanes(robot, e, block, lanes);
+    if (!valid || n == 1) return valid;
+    /* validate.hh:50-64 */
+    float backstep[16];
+    for (size_t j = 0; j < dim; ++j) backstep[j] = vector[j] / (float) (VO_RAKE * n);
+    for (size_t i = 1; i < n; ++i)
+    {
+        for (size_t j = 0; j < dim; ++j)
+            for (int k = 0; k < VO_RAKE; ++k) block[j * VO_RAKE + k] = block[j * VO_RAKE + k] - backstep[j];
+        if (!fkcc_lanes(robot, e, block, lanes)) return 0;
+    }
+    return 1;
+}
+
+int vo_validate_motion(int robot, const vo_env *e, const float *start, const float *goal)
+{
+    const vo_robot *R = &vo_robots[robot];
+    float vector[16];
+    for (size_t j = 0; j < R->dimension; ++j) vector[j] = goal[j] - start[j];
+    return validate_vector(robot, e, start, vector, vo_l2_norm(vector, R->dimension), R->resolution, VO_RAKE);
+}
+
+int vo_validate(int robot, const vo_env *e, const float *q, int check_bounds)
+{
+    const vo_robot *R = &vo_robots[robot];
+    if (check_bounds)
+    {
+        /* robot_helper.hh:258-262 with descale_configuration (robots/panda.hh:82-85): (q - s_a) * d_m in [0, 1] */
+        for (size_t j = 0; j < R->dimension; ++j)
+        {
+            const float t = (q[j] - R->lower[j]) * R->descale[j];
+            if (!(t <= 1.F) || !(t >= 0.F)) return 0;
+        }
+    }
+    /* validate_motion<Robot, rake, 1>(q, q): vector = 0, distance = 0 -> n = 1, all 8 lanes hold q + 0 * percent */
+    float vector[16] = {0};
+    return validate_vector(robot, e, q, vector, 0.F, 1, 1);
+}
+
+void vo_validate_batch(int robot, const vo_env *e, const float *q, size_t n, uint8_t *out)
+{
+    const size_t dim = vo_robots[robot].dimension;
+    for (size_t i = 0; i < n; ++i) out[i] = (uint8_t) vo_validate(robot, e, q + i * dim, 0);
+}
+
+void vo_validate_motion_batch(int robot, const vo_env *e, const float *a, const float *b, size_t n, uint8_t *out)
+{
+    const size_t dim = vo_robots[robot].dimension;
+    for (size_t i = 0; i < n; ++i) out[i] = (uint8_t) vo_validate_motion(robot, e, a + i * dim, b + i * dim);
+}
+
+typedef struct
+{
+    int robot;
+    const vo_env *e;
+    const float *q;
+    size_t n;
+    uint8_t *out;
+} mt_job;
+static void *mt_run(void *p)
+{
+    mt_job *j = (mt_job *) p;
+    vo_validate_batch(j->robot, j->e, j->q, j->n, j->out);
+    return NULL;
+}
+void vo_validate_batch_mt(int robot, const vo_env *e, const float *q, size_t n, uint8_t *out, int threads)
+{
+    if (threads < 1) threads = 1;
+    if (threads > 256) threads = 256;
+    const size_t dim = vo_robots[robot].dimension;
+    pthread_t tid[256];
+    mt_job jobs[256];
+    const size_t per = (n + (size_t) threads - 1) / (size_t) threads;
+    int started = 0;
+    for (int t = 0; t < threads; ++t)
+    {
+        const size_t b = per * (size_t) t;
+        if (b >= n) break;
+        const size_t cnt = (b + per <= n) ? per : n - b;
+        jobs[t] = (mt_job){robot, e, q + b * dim, cnt, out + b};
+        pthread_create(&tid[t], NULL, mt_run, &jobs[t]);
+        started++;
+    }
+    for (int t = 0; t < started; ++t) pthread_join(tid[t], NULL);
+}

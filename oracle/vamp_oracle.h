@@ -1,0 +1,110 @@
+/*
+ * vamp_oracle.h — CPU ORACLE (TEST INFRASTRUCTURE ONLY).
+ *
+ * A plain-C restatement of the reference's motion-validation hot path
+ * (chingchennn/vamp_mvt @ /root/reference; citations are file:line under
+ * src/impl/vamp/).  Only tests/, __graft_entry__.smoke() and bench.py's
+ * `cpu_baseline` leg may load this library, and only as the checker — never
+ * as the thing measured or shipped.  The product path (vamp_mvt_amd/) never
+ * links, imports or calls anything in this directory.
+ *
+ * Parity pins: the FK programs are bit-exact against
+ * the reference's generated robots/<robot>.hh fkcc text evaluated by
+ * tools/ref_fk_eval.py; sin/cos/l2_norm/Halton are checked against the
+ * reference's own vector.hh / halton.hh compiled in place (oracle/_ref); whole
+ * pipeline known answers come from SURVEY.md §8c (sphere cage, Halton counts).
+ * Not pinned by any reference artefact: cuboid/capsule tests and the CAPT
+ * build/query beyond the survey's recorded statistics ("parity unpinned").
+ *
+ * Arithmetic contract: IEEE fp32, one rounding per written operation
+ * (compile with -ffp-contract=off, no fast-math).  The only deliberate
+ * deviation from the reference: `max_extent` in the sorted early-break uses a
+ * correctly rounded sqrt instead of AVX `v * rsqrt_ps(v)` (vector/avx.hh:411-415),
+ * whose low bits are vendor-defined and therefore not reproducible.
+ */
+#ifndef VAMP_ORACLE_H
+#define VAMP_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VO_RAKE 8 /* vamp::FloatVectorWidth on AVX2 (vector.hh:24) */
+
+typedef struct vo_env vo_env;
+
+/* collision/environment.hh:16-88 + bindings/environment.cc:111-163 */
+vo_env *vo_env_create(void);
+void vo_env_destroy(vo_env *e);
+void vo_env_add_sphere(vo_env *e, float x, float y, float z, float r);
+/* 15 floats: x y z | axis_1 xyz | axis_2 xyz | axis_3 xyz | half extents 1..3 (collision/shapes.hh:32-49) */
+void vo_env_add_cuboid(vo_env *e, const float *p15);
+/* 8 floats: x1 y1 z1 | xv yv zv | r | rdv (collision/shapes.hh:128-143) */
+void vo_env_add_capsule(vo_env *e, const float *p8);
+/* collision/capt.hh:296-369; returns 0 on success */
+int vo_env_add_capt(vo_env *e, const float *points_xyz, size_t n, float r_min, float r_max, float r_point);
+
+/* counts after sorting/splitting: spheres, capsules, z_capsules, cuboids, z_cuboids, capts */
+void vo_env_counts(const vo_env *e, size_t counts[6]);
+/* copy the sorted primitive tables (for cross-checking the device upload) */
+size_t vo_env_get_spheres(const vo_env *e, float *out5 /* x y z r min_distance */);
+size_t vo_env_get_cuboids(const vo_env *e, int z_aligned, float *out16 /* 15 params + min_distance */);
+size_t vo_env_get_capsules(const vo_env *e, int z_aligned, float *out9 /* 8 params + min_distance */);
+
+/* CAPT array access (collision/capt.hh:588-623) */
+typedef struct vo_capt_view
+{
+    uint32_t nlog2;
+    uint32_t n_tests;       /* 2^nlog2 - 1 */
+    uint32_t n_leaves;      /* 2^nlog2 */
+    uint32_t n_aff_vectors; /* affordance vectors of VO_RAKE points each */
+    const float *tests;
+    const uint32_t *aff_starts; /* n_leaves + 1 */
+    const float *aabbs;         /* n_leaves * 6: lower xyz, upper xyz */
+    const float *aff_x, *aff_y, *aff_z; /* n_aff_vectors * VO_RAKE */
+    float aabb_top[6];
+    float r_min, r_max, r_point;
+} vo_capt_view;
+int vo_env_capt_view(const vo_env *e, size_t index, vo_capt_view *out);
+/* CAPT::collides (scalar, capt.hh:374-415) and one lane of collides_simd (capt.hh:428-512) */
+int vo_capt_collides(const vo_env *e, size_t index, const float c[3], float r);
+int vo_capt_collides_simd(const vo_env *e, size_t index, const float *cx, const float *cy, const float *cz,
+                          const float *r, int lanes);
+
+/* robots */
+int vo_robot_id(const char *name); /* -1 if unknown */
+size_t vo_robot_dimension(int robot);
+size_t vo_robot_n_spheres(int robot);
+size_t vo_robot_n_total_spheres(int robot);
+size_t vo_robot_resolution(int robot);
+void vo_robot_bounds(int robot, float *lower, float *span);
+
+/* arithmetic contract probes (vector/avx.hh:455-548, vector/interface.hh:447-458, :397-420) */
+float vo_sin(float x);
+float vo_cos(float x);
+float vo_l2_norm(const float *v, size_t dim);
+
+/* Robot::sphere_fk<1> (robots/panda.hh:116-462): out[n_spheres][4] = x y z r */
+void vo_fk(int robot, const float *q, float *out);
+/* FK of fine + bounding spheres as used by fkcc: out[n_total][4] */
+void vo_fk_all(int robot, const float *q, float *out);
+
+/* Robot::fkcc<8> (robots/panda.hh:5226-10262) on a rake given as block[dim][VO_RAKE]; 1 = valid */
+int vo_fkcc_rake(int robot, const vo_env *e, const float *block);
+/* bindings/robot_helper.hh:255-267 (check_bounds optional) */
+int vo_validate(int robot, const vo_env *e, const float *q, int check_bounds);
+/* planning/validate.hh:70-77 with the robot's resolution */
+int vo_validate_motion(int robot, const vo_env *e, const float *start, const float *goal);
+/* batch helpers: out[i] = 1 valid / 0 invalid */
+void vo_validate_batch(int robot, const vo_env *e, const float *q, size_t n, uint8_t *out);
+void vo_validate_motion_batch(int robot, const vo_env *e, const float *a, const float *b, size_t n, uint8_t *out);
+/* same, spread over `threads` pthreads (cpu_baseline leg of bench.py) */
+void vo_validate_batch_mt(int robot, const vo_env *e, const float *q, size_t n, uint8_t *out, int threads);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

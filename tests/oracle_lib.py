@@ -1,0 +1,242 @@
+"""ctypes view of oracle/liboracle.so — TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import
+this.  Nothing under vamp_mvt_amd/ does.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+ORACLE_DIR = os.path.join(_HERE, "..", "oracle")
+_fp = ctypes.POINTER(ctypes.c_float)
+_u8p = ctypes.POINTER(ctypes.c_uint8)
+
+
+def _f(a):
+    return a.ctypes.data_as(_fp)
+
+
+class CaptView(ctypes.Structure):
+    _fields_ = [("nlog2", ctypes.c_uint32), ("n_tests", ctypes.c_uint32), ("n_leaves", ctypes.c_uint32),
+                ("n_aff_vectors", ctypes.c_uint32), ("tests", _fp), ("aff_starts", ctypes.POINTER(ctypes.c_uint32)),
+                ("aabbs", _fp), ("aff_x", _fp), ("aff_y", _fp), ("aff_z", _fp), ("aabb_top", ctypes.c_float * 6),
+                ("r_min", ctypes.c_float), ("r_max", ctypes.c_float), ("r_point", ctypes.c_float)]
+
+
+def build_oracle():
+    """Compile oracle/liboracle.so if missing or stale (gcc only; no GPU, no reference needed)."""
+    so = os.path.join(ORACLE_DIR, "liboracle.so")
+    srcs = [os.path.join(ORACLE_DIR, f) for f in ("vamp_oracle.c", "vamp_oracle.h", "gen/robots_gen.inc")]
+    if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "liboracle.so"], stdout=subprocess.DEVNULL)
+    return so
+
+
+class Oracle:
+    def __init__(self):
+        L = ctypes.CDLL(build_oracle())
+        self.L = L
+        L.vo_env_create.restype = ctypes.c_void_p
+        L.vo_env_destroy.argtypes = [ctypes.c_void_p]
+        L.vo_env_add_sphere.argtypes = [ctypes.c_void_p] + [ctypes.c_float] * 4
+        L.vo_env_add_cuboid.argtypes = [ctypes.c_void_p, _fp]
+        L.vo_env_add_capsule.argtypes = [ctypes.c_void_p, _fp]
+        L.vo_env_add_capt.argtypes = [ctypes.c_void_p, _fp, ctypes.c_size_t] + [ctypes.c_float] * 3
+        L.vo_env_add_capt.restype = ctypes.c_int
+        L.vo_env_counts.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_size_t)]
+        for fn in ("vo_env_get_spheres",):
+            getattr(L, fn).argtypes = [ctypes.c_void_p, _fp]
+            getattr(L, fn).restype = ctypes.c_size_t
+        for fn in ("vo_env_get_cuboids", "vo_env_get_capsules"):
+            getattr(L, fn).argtypes = [ctypes.c_void_p, ctypes.c_int, _fp]
+            getattr(L, fn).restype = ctypes.c_size_t
+        L.vo_env_capt_view.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(CaptView)]
+        L.vo_capt_collides.argtypes = [ctypes.c_void_p, ctypes.c_size_t, _fp, ctypes.c_float]
+        L.vo_capt_collides_simd.argtypes = [ctypes.c_void_p, ctypes.c_size_t, _fp, _fp, _fp, _fp, ctypes.c_int]
+        L.vo_robot_id.argtypes = [ctypes.c_char_p]
+        for fn in ("vo_robot_dimension", "vo_robot_n_spheres", "vo_robot_n_total_spheres", "vo_robot_resolution"):
+            getattr(L, fn).argtypes = [ctypes.c_int]
+            getattr(L, fn).restype = ctypes.c_size_t
+        L.vo_robot_bounds.argtypes = [ctypes.c_int, _fp, _fp]
+        for fn in ("vo_sin", "vo_cos"):
+            getattr(L, fn).argtypes = [ctypes.c_float]
+            getattr(L, fn).restype = ctypes.c_float
+        L.vo_l2_norm.argtypes = [_fp, ctypes.c_size_t]
+        L.vo_l2_norm.restype = ctypes.c_float
+        L.vo_fk.argtypes = [ctypes.c_int, _fp, _fp]
+        L.vo_fk_all.argtypes = [ctypes.c_int, _fp, _fp]
+        L.vo_fkcc_rake.argtypes = [ctypes.c_int, ctypes.c_void_p, _fp]
+        L.vo_validate.argtypes = [ctypes.c_int, ctypes.c_void_p, _fp, ctypes.c_int]
+        L.vo_validate_motion.argtypes = [ctypes.c_int, ctypes.c_void_p, _fp, _fp]
+        L.vo_validate_batch.argtypes = [ctypes.c_int, ctypes.c_void_p, _fp, ctypes.c_size_t, _u8p]
+        L.vo_validate_motion_batch.argtypes = [ctypes.c_int, ctypes.c_void_p, _fp, _fp, ctypes.c_size_t, _u8p]
+        L.vo_validate_batch_mt.argtypes = [ctypes.c_int, ctypes.c_void_p, _fp, ctypes.c_size_t, _u8p, ctypes.c_int]
+
+    # -- robots -------------------------------------------------------------
+    def robot(self, name):
+        rid = self.L.vo_robot_id(name.encode())
+        if rid < 0:
+            raise KeyError(name)
+        return rid
+
+    def dimension(self, rid):
+        return self.L.vo_robot_dimension(rid)
+
+    def n_spheres(self, rid):
+        return self.L.vo_robot_n_spheres(rid)
+
+    def n_total_spheres(self, rid):
+        return self.L.vo_robot_n_total_spheres(rid)
+
+    def resolution(self, rid):
+        return self.L.vo_robot_resolution(rid)
+
+    def bounds(self, rid):
+        d = self.dimension(rid)
+        lo, span = np.zeros(d, np.float32), np.zeros(d, np.float32)
+        self.L.vo_robot_bounds(rid, _f(lo), _f(span))
+        return lo, span
+
+    def sin(self, x):
+        return np.array([self.L.vo_sin(float(v)) for v in np.asarray(x, np.float32).ravel()], np.float32)
+
+    def cos(self, x):
+        return np.array([self.L.vo_cos(float(v)) for v in np.asarray(x, np.float32).ravel()], np.float32)
+
+    def l2_norm(self, v):
+        v = np.ascontiguousarray(v, np.float32)
+        return float(self.L.vo_l2_norm(_f(v), v.size))
+
+    def fk(self, rid, q):
+        q = np.ascontiguousarray(q, np.float32)
+        out = np.zeros((self.n_spheres(rid), 4), np.float32)
+        self.L.vo_fk(rid, _f(q), _f(out))
+        return out
+
+    def fk_all(self, rid, q):
+        q = np.ascontiguousarray(q, np.float32)
+        out = np.zeros((self.n_total_spheres(rid), 4), np.float32)
+        self.L.vo_fk_all(rid, _f(q), _f(out))
+        return out
+
+    # -- environment ----------------------------------------------------------
+    def env(self):
+        return OracleEnv(self)
+
+    def fkcc_rake(self, rid, env, block):
+        """block: [dim][8]"""
+        block = np.ascontiguousarray(block, np.float32)
+        return bool(self.L.vo_fkcc_rake(rid, env.h, _f(block)))
+
+    def validate(self, rid, env, q, check_bounds=False):
+        q = np.ascontiguousarray(q, np.float32)
+        return bool(self.L.vo_validate(rid, env.h, _f(q), int(check_bounds)))
+
+    def validate_motion(self, rid, env, a, b):
+        a = np.ascontiguousarray(a, np.float32)
+        b = np.ascontiguousarray(b, np.float32)
+        return bool(self.L.vo_validate_motion(rid, env.h, _f(a), _f(b)))
+
+    def validate_batch(self, rid, env, q, threads=1):
+        q = np.ascontiguousarray(q, np.float32)
+        out = np.zeros(q.shape[0], np.uint8)
+        if threads > 1:
+            self.L.vo_validate_batch_mt(rid, env.h, _f(q), q.shape[0], out.ctypes.data_as(_u8p), threads)
+        else:
+            self.L.vo_validate_batch(rid, env.h, _f(q), q.shape[0], out.ctypes.data_as(_u8p))
+        return out.astype(bool)
+
+    def validate_motion_batch(self, rid, env, a, b):
+        a = np.ascontiguousarray(a, np.float32)
+        b = np.ascontiguousarray(b, np.float32)
+        out = np.zeros(a.shape[0], np.uint8)
+        self.L.vo_validate_motion_batch(rid, env.h, _f(a), _f(b), a.shape[0], out.ctypes.data_as(_u8p))
+        return out.astype(bool)
+
+
+class OracleEnv:
+    def __init__(self, oracle):
+        self.o = oracle
+        self.h = ctypes.c_void_p(oracle.L.vo_env_create())
+
+    def __del__(self):
+        try:
+            self.o.L.vo_env_destroy(self.h)
+        except Exception:
+            pass
+
+    def add_sphere(self, x, y, z, r):
+        self.o.L.vo_env_add_sphere(self.h, float(x), float(y), float(z), float(r))
+
+    def add_cuboid(self, p15):
+        p = np.ascontiguousarray(p15, np.float32)
+        assert p.size == 15
+        self.o.L.vo_env_add_cuboid(self.h, _f(p))
+
+    def add_capsule(self, p8):
+        p = np.ascontiguousarray(p8, np.float32)
+        assert p.size == 8
+        self.o.L.vo_env_add_capsule(self.h, _f(p))
+
+    def add_capt(self, points, r_min, r_max, r_point):
+        p = np.ascontiguousarray(points, np.float32)
+        rc = self.o.L.vo_env_add_capt(self.h, _f(p), p.shape[0], float(r_min), float(r_max), float(r_point))
+        if rc != 0:
+            raise ValueError("capt build failed")
+
+    def counts(self):
+        c = (ctypes.c_size_t * 6)()
+        self.o.L.vo_env_counts(self.h, c)
+        return list(c)
+
+    def spheres(self):
+        n = self.counts()[0]
+        out = np.zeros((max(n, 1), 5), np.float32)
+        self.o.L.vo_env_get_spheres(self.h, _f(out))
+        return out[:n]
+
+    def cuboids(self, z_aligned):
+        n = self.counts()[4 if z_aligned else 3]
+        out = np.zeros((max(n, 1), 16), np.float32)
+        self.o.L.vo_env_get_cuboids(self.h, int(z_aligned), _f(out))
+        return out[:n]
+
+    def capsules(self, z_aligned):
+        n = self.counts()[2 if z_aligned else 1]
+        out = np.zeros((max(n, 1), 9), np.float32)
+        self.o.L.vo_env_get_capsules(self.h, int(z_aligned), _f(out))
+        return out[:n]
+
+    def capt(self, index=0):
+        v = CaptView()
+        if self.o.L.vo_env_capt_view(self.h, index, ctypes.byref(v)) != 0:
+            raise IndexError(index)
+        n_l, n_a = v.n_leaves, v.n_aff_vectors
+        return dict(
+            nlog2=v.nlog2,
+            tests=np.ctypeslib.as_array(v.tests, (v.n_tests,)).copy(),
+            aff_starts=np.ctypeslib.as_array(v.aff_starts, (n_l + 1,)).copy(),
+            aabbs=np.ctypeslib.as_array(v.aabbs, (n_l, 6)).copy(),
+            aff=np.stack([np.ctypeslib.as_array(p, (n_a, 8)).copy() for p in (v.aff_x, v.aff_y, v.aff_z)]),
+            aabb_top=np.array(list(v.aabb_top), np.float32), r_min=v.r_min, r_max=v.r_max, r_point=v.r_point)
+
+    def capt_collides(self, c, r, index=0):
+        c = np.ascontiguousarray(c, np.float32)
+        return bool(self.o.L.vo_capt_collides(self.h, index, _f(c), float(r)))
+
+    def capt_collides_simd(self, cx, cy, cz, r, index=0):
+        cx, cy, cz, r = (np.ascontiguousarray(a, np.float32) for a in (cx, cy, cz, r))
+        return bool(self.o.L.vo_capt_collides_simd(self.h, index, _f(cx), _f(cy), _f(cz), _f(r), cx.size))
+
+
+SPHERE_CAGE = [  # reference scripts/sphere_cage_example.py:16-31 (problem data), radius 0.2
+    [0.55, 0, 0.25], [0.35, 0.35, 0.25], [0, 0.55, 0.25], [-0.55, 0, 0.25], [-0.35, -0.35, 0.25], [0, -0.55, 0.25],
+    [0.35, -0.35, 0.25], [0.35, 0.35, 0.8], [0, 0.55, 0.8], [-0.35, 0.35, 0.8], [-0.55, 0, 0.8], [-0.35, -0.35, 0.8],
+    [0, -0.55, 0.8], [0.35, -0.35, 0.8]]
+CAGE_START = [0., -0.785, 0., -2.356, 0., 1.571, 0.785]
+CAGE_GOAL = [2.35, 1., 0., -0.8, 0, 2.5, 0.785]

@@ -87,6 +87,9 @@ def check(name, n=20000, seed=1, verbose=True):
     if not np.array_equal(np.array(model["span"], np.float32), span):
         print("  spans differ", model["span"], span)
         ok = False
+    if not np.array_equal(np.array(model["descale"], np.float32), np.array(consts["d_m"], np.float32)):
+        print("  descale differs", model["descale"], consts["d_m"])
+        ok = False
     q = (rng.random((n, len(lo)), dtype=np.float32) * span + lo).astype(np.float32)
     yref = R.Evaluator(prog, rv).run(q)  # [n_y, N]
     ymod = eval_model(model, q, rv)  # [S, 4, N]

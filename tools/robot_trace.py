@@ -652,6 +652,7 @@ def to_json(tr: Traced):
         lower=[float(np.float32(v)) for v in tr.lower],
         upper=[float(np.float32(v)) for v in tr.upper],
         span=[float(np.float32(u - l)) for u, l in zip(tr.upper, tr.lower)],
+        descale=[float(np.float32(1.0 / (u - l))) for u, l in zip(tr.upper, tr.lower)],
         links=tr.link_order,
         sphere_link=[tr.link_order.index(sp["link"]) for sp in tr.spheres],
         radii=radii,
