@@ -1,0 +1,126 @@
+/*
+ * vamp_mvt_amd.h — C ABI of the MI355X-native motion-validation hot path.
+ *
+ * Drop-in boundary for one path of chingchennn/vamp_mvt: configuration-rake forward kinematics + sphere
+ * collision check (+ CAPT point-cloud query).  The reference exposes this path only through its nanobind
+ * module `vamp._core` (no C ABI exists there); each entry point below names the reference interface it
+ * replaces (file:line under /root/reference/src/impl/vamp/).  INTEGRATION.md shows the binding a maintainer
+ * would add on the reference side.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, opaque handles, `int` status (0 = VMV_OK); nothing throws/aborts.
+ *   - `d_*` pointers are DEVICE pointers (HBM) on the current HIP device; `*_host` variants take host
+ *     buffers and do the H2D/D2H copies themselves.  `stream` is a hipStream_t passed as void* (NULL = default).
+ *   - configurations are fp32, row-major [n][dimension], joint values in radians / metres (not normalised).
+ *   - validity results are packed bitmasks, little-endian within 64-bit words: bit (i % 64) of word (i / 64)
+ *     is 1 iff configuration/edge i is VALID (collision free).  d_bits must hold ceil(n / 64) words.
+ *   - an environment is immutable after vmv_env_finalize() and may then be used from any thread/stream.
+ *   - there is no CPU fallback: every compute entry point fails with VMV_ERR_NO_DEVICE without a GPU.
+ */
+#ifndef VAMP_MVT_AMD_H
+#define VAMP_MVT_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum
+{
+    VMV_OK = 0,
+    VMV_ERR_INVALID_ARGUMENT = 1,
+    VMV_ERR_NO_DEVICE = 2,
+    VMV_ERR_HIP = 3,
+    VMV_ERR_CAPACITY = 4,      /* environment does not fit the on-chip staging budget */
+    VMV_ERR_NOT_FINALIZED = 5,
+    VMV_ERR_UNKNOWN_ROBOT = 6,
+    VMV_ERR_FINALIZED = 7      /* mutation after finalize */
+};
+
+const char *vmv_status_string(int status);
+int vmv_abi_version(void);
+/* last HIP error text of the calling thread (empty if none) */
+const char *vmv_last_error(void);
+
+/* ---- devices ----------------------------------------------------------------------------------------- */
+int vmv_device_count(int *count);
+int vmv_set_device(int device);
+
+/* ---- robots (replaces the per-robot submodule constants, bindings/robot_helper.hh:326-360) ------------ */
+int vmv_num_robots(void);
+const char *vmv_robot_name(int robot);
+int vmv_robot_id(const char *name);           /* -1 if unknown ("panda", "ur5", "fetch", "baxter") */
+int vmv_robot_dimension(int robot);           /* Robot::dimension */
+int vmv_robot_n_spheres(int robot);           /* Robot::n_spheres */
+int vmv_robot_resolution(int robot);          /* Robot::resolution */
+int vmv_robot_min_max_radii(int robot, float *min_radius, float *max_radius);
+/* lower[d], span[d], descale[d]: Robot::s_a, s_m, d_m (robots/panda.hh:50-75) */
+int vmv_robot_bounds(int robot, float *lower, float *span, float *descale);
+const char *vmv_robot_joint_name(int robot, int joint);
+const char *vmv_robot_end_effector(int robot);
+
+/* ---- environment (replaces vamp.Environment, bindings/environment.cc:111-163) -------------------------- */
+typedef struct vmv_env vmv_env;
+
+int vmv_env_create(vmv_env **out);
+int vmv_env_destroy(vmv_env *env);
+/* Environment.add_sphere(Sphere(center, r)) — environment.cc:113-119, collision/shapes.hh:226-239 */
+int vmv_env_add_sphere(vmv_env *env, float x, float y, float z, float r);
+/* Environment.add_cuboid — environment.cc:120-133.  15 floats: centre xyz | axis_1 xyz | axis_2 xyz |
+ * axis_3 xyz | half extents 1..3 (collision/shapes.hh:32-49).  Filed as z-aligned iff axis_3_z == 1. */
+int vmv_env_add_cuboid(vmv_env *env, const float *params15);
+/* Environment.add_capsule — environment.cc:134-147.  8 floats: x1 y1 z1 | xv yv zv | r | rdv
+ * (collision/shapes.hh:128-143).  Filed as z-aligned iff xv == 0 and yv == 0. */
+int vmv_env_add_capsule(vmv_env *env, const float *params8);
+/* Environment.add_capt_pointcloud(points, r_min, r_max, r_point) -> build ns — environment.cc:152-163,
+ * collision/capt.hh:296-369.  points: host pointer, [n][3] fp32. */
+int vmv_env_add_capt_pointcloud(vmv_env *env, const float *points_xyz, size_t n, float r_min, float r_max,
+                                float r_point, uint64_t *build_nanoseconds);
+/* Sorts every primitive list by min_distance (collision/environment.hh:46-72) and uploads the environment to
+ * the current device.  The reference re-sorts on every add and converts per call (robot_helper.hh:266). */
+int vmv_env_finalize(vmv_env *env);
+/* counts[6]: spheres, capsules, z_capsules, cuboids, z_cuboids, capt point clouds */
+int vmv_env_counts(const vmv_env *env, size_t *counts6);
+/* sorted host copies for inspection: spheres [n][5] (x y z r min_distance), cuboids [n][16], capsules [n][9] */
+int vmv_env_get_spheres(const vmv_env *env, float *out, size_t capacity, size_t *n);
+int vmv_env_get_cuboids(const vmv_env *env, int z_aligned, float *out, size_t capacity, size_t *n);
+int vmv_env_get_capsules(const vmv_env *env, int z_aligned, float *out, size_t capacity, size_t *n);
+/* CAPT arrays of point cloud `index` (collision/capt.hh:588-623) — sizes first, then copies (NULL = skip) */
+int vmv_env_capt_sizes(const vmv_env *env, size_t index, uint32_t *nlog2, uint32_t *n_aff_vectors);
+int vmv_env_capt_arrays(const vmv_env *env, size_t index, float *tests, uint32_t *aff_starts, float *aabbs,
+                        float *aff_x, float *aff_y, float *aff_z, float *aabb_top6);
+
+/* ---- batched hot path ---------------------------------------------------------------------------------- */
+/* <robot>.fk(q) -> list[Sphere] — robot_helper.hh:234-247, Robot::sphere_fk (robots/panda.hh:116-462).
+ * d_out: [n][n_spheres][4] = x y z r. */
+int vmv_fk_batch(int robot, const float *d_q, size_t n, float *d_out, void *stream);
+/* <robot>.validate(q, env) — robot_helper.hh:255-267 -> validate_motion<Robot, 8, 1>(q, q, env)
+ * (planning/validate.hh:70-77) -> Robot::fkcc (robots/panda.hh:5226-10262).  One bit per configuration. */
+int vmv_validate_batch(int robot, const vmv_env *env, const float *d_q, size_t n, uint64_t *d_bits, void *stream);
+/* validate_motion<Robot, 8, Robot::resolution>(start, goal, env) — planning/validate.hh:24-77, the call every
+ * planner makes per edge (rrtc.hh:136-140, prm.hh:59, fcit.hh:238 ...).  One bit per edge. */
+int vmv_validate_motion_batch(int robot, const vmv_env *env, const float *d_start, const float *d_goal, size_t n,
+                              uint64_t *d_bits, void *stream);
+
+/* host-buffer variants (copies included; the PCIe-inclusive path) */
+int vmv_fk_batch_host(int robot, const float *q, size_t n, float *out);
+int vmv_validate_batch_host(int robot, const vmv_env *env, const float *q, size_t n, uint64_t *bits);
+int vmv_validate_motion_batch_host(int robot, const vmv_env *env, const float *start, const float *goal, size_t n,
+                                   uint64_t *bits);
+
+/* ---- measurement support (bench.py) ---------------------------------------------------------------------- */
+/* Runs vmv_validate_batch `iters` times on `stream` between two HIP events recorded on that same stream and
+ * returns the average kernel time in milliseconds. */
+int vmv_time_validate_batch(int robot, const vmv_env *env, const float *d_q, size_t n, uint64_t *d_bits, int iters,
+                            void *stream, float *avg_ms);
+/* fills d_q[n][dimension] with uniform configurations inside the joint bounds (splitmix64 counter RNG) */
+int vmv_fill_uniform_configs(int robot, float *d_q, size_t n, uint64_t seed, void *stream);
+/* name of the dominant kernel symbol for a robot (to match rocprofv3 --kernel-trace rows) */
+const char *vmv_kernel_name(int robot, const char *entry_point);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -902,7 +902,7 @@ static int validate_vector(int robot, const vo_env *e, const float *start, const
 {
     const vo_robot *R = &vo_robots[robot];
     const size_t dim = R->dimension;
-    float block[16 * VO_RAKE];
+    float block[16 * VO_RAKE] = {0};
     /* validate.hh:31-39: block[i] = start[i] + vector[i] * percents, percents[k] = (k+1)/8 */
     for (size_t i = 0; i < dim; ++i)
         for (int k = 0; k < VO_RAKE; ++k)

@@ -1,0 +1,422 @@
+"""vamp_mvt_amd — MI355X-native motion validation behind the `vamp` names for this path.
+
+Host-side mirror of the reference's Python surface for ONE hot path (reference `vamp._core`,
+src/impl/vamp/bindings/{environment.cc,robot_helper.hh}): `Sphere`, `Cuboid`, `Cylinder`, `Environment`
+and the per-robot modules `panda`, `ur5`, `fetch`, `baxter` with `validate`, `fk`, `dimension`,
+`resolution`, `n_spheres`, `min_max_radii`, `joint_names`, `end_effector` — plus the batched calls the
+reference lists as planned (`README.md:346`): `validate_batch`, `validate_motion_batch`, `fk_batch`.
+
+Everything computes on the GPU through the C ABI (include/vamp_mvt_amd.h -> libvamp_mvt_amd.so).  There is
+no CPU path: without a HIP device every compute call raises VmvError(VMV_ERR_NO_DEVICE).
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+import sys
+import types
+
+import numpy as np
+
+from . import _lib
+from ._lib import VmvError, check, lib
+
+__all__ = ["Sphere", "Cuboid", "Cylinder", "Environment", "robots", "device_count", "set_device", "abi_version",
+           "VmvError", "unpack_bits", "POINT_RADIUS"]
+
+POINT_RADIUS = 0.0025  # reference src/vamp/constants.py:25
+
+
+def abi_version() -> int:
+    return lib.vmv_abi_version()
+
+
+def device_count() -> int:
+    n = ctypes.c_int(0)
+    lib.vmv_device_count(ctypes.byref(n))
+    return n.value
+
+
+def set_device(index: int) -> None:
+    check(lib.vmv_set_device(int(index)), "vmv_set_device")
+
+
+def robots():
+    """reference bindings/python.cc.in `robots()`"""
+    return [lib.vmv_robot_name(i).decode() for i in range(lib.vmv_num_robots())]
+
+
+def _f32(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    if shape is not None and tuple(a.shape) != tuple(shape):
+        raise TypeError(f"expected float32 array of shape {shape}, got {a.shape}")
+    return a
+
+
+def _fp(a):
+    return a.ctypes.data_as(_lib.c_float_p)
+
+
+def unpack_bits(words: np.ndarray, n: int) -> np.ndarray:
+    """uint64 validity words (bit i%64 of word i//64) -> bool[n]."""
+    b = np.unpackbits(np.ascontiguousarray(words, dtype="<u8").view(np.uint8), bitorder="little")
+    return b[:n].astype(bool)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# shapes (reference collision/shapes.hh, collision/factory.hh; Python classes of bindings/environment.cc:22-99)
+# ---------------------------------------------------------------------------------------------------------
+def _rotation_zyx(rho, theta, phi):
+    """AngleAxis(phi, Z) * AngleAxis(theta, Y) * AngleAxis(rho, X) in fp32 (collision/factory.hh:37-39).
+
+    Parity note: the reference evaluates this with Eigen's float AngleAxis/matrix products; Eigen is not
+    available offline, so the result is equal to tolerance, not pinned bit-for-bit ("parity unpinned").
+    Callers that need bit-exact primitives pass canonical parameters (`Cuboid.from_canonical`)."""
+    f = np.float32
+    cr, sr = f(math.cos(f(rho))), f(math.sin(f(rho)))
+    ct, st = f(math.cos(f(theta))), f(math.sin(f(theta)))
+    cp, sp = f(math.cos(f(phi))), f(math.sin(f(phi)))
+    rx = np.array([[1, 0, 0], [0, cr, -sr], [0, sr, cr]], np.float32)
+    ry = np.array([[ct, 0, st], [0, 1, 0], [-st, 0, ct]], np.float32)
+    rz = np.array([[cp, -sp, 0], [sp, cp, 0], [0, 0, 1]], np.float32)
+    return (rz @ ry @ rx).astype(np.float32)
+
+
+class Sphere:
+    """vamp.Sphere(center, radius) — bindings/environment.cc:22-40."""
+
+    def __init__(self, center, radius):
+        c = _f32(center, (3,))
+        self.x, self.y, self.z, self.r = float(c[0]), float(c[1]), float(c[2]), float(np.float32(radius))
+        self.name = ""
+
+    @property
+    def position(self):
+        return [self.x, self.y, self.z]
+
+    @property
+    def min_distance(self):
+        f = np.float32
+        return float(np.sqrt(f(self.x) * f(self.x) + f(self.y) * f(self.y) + f(self.z) * f(self.z)) - f(self.r))
+
+    def __repr__(self):
+        return f"Sphere(({self.x}, {self.y}, {self.z}), r={self.r})"
+
+
+class Cuboid:
+    """vamp.Cuboid(center, euler_xyz, half_extents) — collision/factory.hh:26-101."""
+
+    def __init__(self, center, euler_xyz, half_extents):
+        c, e, h = _f32(center, (3,)), _f32(euler_xyz, (3,)), _f32(half_extents, (3,))
+        rot = _rotation_zyx(e[0], e[1], e[2])
+        self.params = np.concatenate([c, rot[:, 0], rot[:, 1], rot[:, 2], h]).astype(np.float32)
+        self.name = ""
+
+    @classmethod
+    def from_canonical(cls, params15):
+        """centre xyz | axis_1 xyz | axis_2 xyz | axis_3 xyz | half extents (collision/shapes.hh:32-49)."""
+        self = cls.__new__(cls)
+        self.params = _f32(params15, (15,)).copy()
+        self.name = ""
+        return self
+
+    x = property(lambda s: float(s.params[0]))
+    y = property(lambda s: float(s.params[1]))
+    z = property(lambda s: float(s.params[2]))
+
+
+class Cylinder:
+    """vamp.Cylinder(center, euler_xyz, radius, length) | Cylinder(endpoint1, endpoint2, radius)
+    — collision/factory.hh:104-223; the environment treats it as a capsule (environment.cc:134-147)."""
+
+    def __init__(self, *args):
+        f = np.float32
+        if len(args) == 4:
+            c, e = _f32(args[0], (3,)), _f32(args[1], (3,))
+            radius, length = f(args[2]), f(args[3])
+            rot = _rotation_zyx(e[0], e[1], e[2])
+            half = f(length / f(2))
+            p1 = (c + rot[:, 2] * half).astype(np.float32)
+            p2 = (c - rot[:, 2] * half).astype(np.float32)
+        elif len(args) == 3:
+            p1, p2, radius = _f32(args[0], (3,)), _f32(args[1], (3,)), f(args[2])
+        else:
+            raise TypeError("Cylinder(center, euler_xyz, radius, length) or Cylinder(endpoint1, endpoint2, radius)")
+        v = (p2 - p1).astype(np.float32)
+        dot = f(f(v[0] * v[0]) + f(v[1] * v[1])) + f(v[2] * v[2])
+        rdv = f(1.0 / float(dot))  # static_cast<float>(1.0 / dot): double division, then narrowed
+        self.params = np.array([p1[0], p1[1], p1[2], v[0], v[1], v[2], radius, rdv], np.float32)
+        self.name = ""
+
+    @classmethod
+    def from_canonical(cls, params8):
+        """x1 y1 z1 | xv yv zv | r | rdv (collision/shapes.hh:128-143)."""
+        self = cls.__new__(cls)
+        self.params = _f32(params8, (8,)).copy()
+        self.name = ""
+        return self
+
+
+class Environment:
+    """vamp.Environment — bindings/environment.cc:111-163 (write-only from Python there, too).
+
+    Host-side this is a recipe; the device image is (re)built lazily by the C ABI on first use after a change
+    (the reference re-sorts on every add and converts the whole environment on every call)."""
+
+    def __init__(self):
+        self._ops = []
+        self._handle = None
+        self._device = None
+
+    # -- mutation ------------------------------------------------------------------------------------------
+    def _dirty(self):
+        if self._handle is not None:
+            lib.vmv_env_destroy(self._handle)
+            self._handle = None
+
+    def add_sphere(self, sphere: Sphere):
+        self._ops.append(("sphere", (sphere.x, sphere.y, sphere.z, sphere.r)))
+        self._dirty()
+
+    def add_cuboid(self, cuboid: Cuboid):
+        self._ops.append(("cuboid", cuboid.params.copy()))
+        self._dirty()
+
+    def add_capsule(self, capsule: Cylinder):
+        self._ops.append(("capsule", capsule.params.copy()))
+        self._dirty()
+
+    def add_capt_pointcloud(self, points, r_min, r_max, r_point):
+        """-> CAPT build time in nanoseconds (environment.cc:152-163)."""
+        pts = _f32(points)
+        if pts.ndim != 2 or pts.shape[1] != 3:
+            raise TypeError("points must be [n][3]")
+        self._ops.append(("capt", (pts.copy(), float(r_min), float(r_max), float(r_point))))
+        self._dirty()
+        # build once now to report the time, as the reference does
+        h = ctypes.c_void_p()
+        check(lib.vmv_env_create(ctypes.byref(h)), "vmv_env_create")
+        ns = ctypes.c_uint64(0)
+        try:
+            check(lib.vmv_env_add_capt_pointcloud(h, _fp(pts), pts.shape[0], r_min, r_max, r_point, ctypes.byref(ns)),
+                  "vmv_env_add_capt_pointcloud")
+        finally:
+            lib.vmv_env_destroy(h)
+        return int(ns.value)
+
+    def __del__(self):
+        try:
+            self._dirty()
+        except Exception:
+            pass
+
+    # -- device image ----------------------------------------------------------------------------------------
+    def _build(self, finalize=True):
+        h = ctypes.c_void_p()
+        check(lib.vmv_env_create(ctypes.byref(h)), "vmv_env_create")
+        try:
+            for kind, arg in self._ops:
+                if kind == "sphere":
+                    check(lib.vmv_env_add_sphere(h, *arg), "vmv_env_add_sphere")
+                elif kind == "cuboid":
+                    check(lib.vmv_env_add_cuboid(h, _fp(arg)), "vmv_env_add_cuboid")
+                elif kind == "capsule":
+                    check(lib.vmv_env_add_capsule(h, _fp(arg)), "vmv_env_add_capsule")
+                else:
+                    pts, r_min, r_max, r_point = arg
+                    check(lib.vmv_env_add_capt_pointcloud(h, _fp(pts), pts.shape[0], r_min, r_max, r_point, None),
+                          "vmv_env_add_capt_pointcloud")
+            if finalize:
+                check(lib.vmv_env_finalize(h), "vmv_env_finalize")
+        except Exception:
+            lib.vmv_env_destroy(h)
+            raise
+        return h
+
+    def handle(self):
+        """Finalized C-ABI handle (sorted + uploaded to the current device)."""
+        if self._handle is None:
+            self._handle = self._build()
+        return self._handle
+
+    # -- inspection (host tables; no GPU needed) ----------------------------------------------------------------
+    def host_tables(self):
+        """Sorted primitive tables as the kernels see them (built without uploading)."""
+        h = self._build(finalize=False)
+        try:
+            counts = (ctypes.c_size_t * 6)()
+            check(lib.vmv_env_counts(h, counts), "vmv_env_counts")
+            n = ctypes.c_size_t(0)
+            out = {}
+            sp = np.zeros((max(counts[0], 1), 5), np.float32)
+            lib.vmv_env_get_spheres(h, _fp(sp), counts[0], ctypes.byref(n))
+            out["spheres"] = sp[:counts[0]]
+            for key, z, cnt, width, fn in (("cuboids", 0, counts[3], 16, lib.vmv_env_get_cuboids),
+                                           ("z_cuboids", 1, counts[4], 16, lib.vmv_env_get_cuboids),
+                                           ("capsules", 0, counts[1], 9, lib.vmv_env_get_capsules),
+                                           ("z_capsules", 1, counts[2], 9, lib.vmv_env_get_capsules)):
+                a = np.zeros((max(cnt, 1), width), np.float32)
+                fn(h, z, _fp(a), cnt, ctypes.byref(n))
+                out[key] = a[:cnt]
+            capts = []
+            for i in range(counts[5]):
+                nlog2, naff = ctypes.c_uint32(0), ctypes.c_uint32(0)
+                check(lib.vmv_env_capt_sizes(h, i, ctypes.byref(nlog2), ctypes.byref(naff)), "vmv_env_capt_sizes")
+                leaves = 1 << nlog2.value
+                t = np.zeros(leaves - 1, np.float32)
+                st = np.zeros(leaves + 1, np.uint32)
+                bb = np.zeros((leaves, 6), np.float32)
+                aff = np.zeros((3, naff.value, 8), np.float32)
+                top = np.zeros(6, np.float32)
+                check(lib.vmv_env_capt_arrays(h, i, _fp(t), st.ctypes.data_as(_lib.c_u32_p), _fp(bb), _fp(aff[0]),
+                                              _fp(aff[1]), _fp(aff[2]), _fp(top)), "vmv_env_capt_arrays")
+                capts.append(dict(nlog2=nlog2.value, tests=t, aff_starts=st, aabbs=bb, aff=aff, aabb_top=top))
+            out["capt"] = capts
+            return out
+        finally:
+            lib.vmv_env_destroy(h)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# per-robot modules (reference bindings/robot_helper.hh:326-597, path subset + batched calls)
+# ---------------------------------------------------------------------------------------------------------
+def _is_torch_cuda(x):
+    t = sys.modules.get("torch")
+    return t is not None and isinstance(x, t.Tensor) and x.is_cuda
+
+
+class _Robot(types.ModuleType):
+    def __init__(self, name: str):
+        super().__init__(f"{__name__}.{name}")
+        self._id = lib.vmv_robot_id(name.encode())
+        if self._id < 0:
+            raise ImportError(f"robot {name} missing from the library")
+        self._name = name
+        self._dim = lib.vmv_robot_dimension(self._id)
+        self._ns = lib.vmv_robot_n_spheres(self._id)
+        lo, sp, ds = (np.zeros(self._dim, np.float32) for _ in range(3))
+        check(lib.vmv_robot_bounds(self._id, _fp(lo), _fp(sp), _fp(ds)), "vmv_robot_bounds")
+        self._lower, self._span, self._descale = lo, sp, ds
+
+    # constants ---------------------------------------------------------------------------------------------
+    def dimension(self):
+        return self._dim
+
+    def resolution(self):
+        return lib.vmv_robot_resolution(self._id)
+
+    def n_spheres(self):
+        return self._ns
+
+    def min_max_radii(self):
+        a, b = ctypes.c_float(0), ctypes.c_float(0)
+        check(lib.vmv_robot_min_max_radii(self._id, ctypes.byref(a), ctypes.byref(b)), "vmv_robot_min_max_radii")
+        return (a.value, b.value)
+
+    def joint_names(self):
+        return [lib.vmv_robot_joint_name(self._id, j).decode() for j in range(self._dim)]
+
+    def end_effector(self):
+        return lib.vmv_robot_end_effector(self._id).decode()
+
+    def lower_bounds(self):
+        return self._lower.copy()
+
+    def upper_bounds(self):
+        return (self._lower + self._span).astype(np.float32)
+
+    # single-configuration calls (drop-in names) --------------------------------------------------------------
+    def validate(self, configuration, environment: Environment | None = None, check_bounds: bool = False) -> bool:
+        """<robot>.validate(q, env=Environment(), check_bounds=False) — robot_helper.hh:255-267."""
+        q = _f32(configuration, (self._dim,))
+        if check_bounds:
+            t = ((q - self._lower) * self._descale).astype(np.float32)  # descale_configuration, panda.hh:82-85
+            if not (bool((t <= np.float32(1)).all()) and bool((t >= np.float32(0)).all())):
+                return False
+        return bool(self.validate_batch(q[None, :], environment)[0])
+
+    def validate_motion(self, start, goal, environment: Environment | None = None) -> bool:
+        """validate_motion<Robot, 8, resolution>(start, goal, env) — planning/validate.hh:70-77."""
+        a, b = _f32(start, (self._dim,)), _f32(goal, (self._dim,))
+        return bool(self.validate_motion_batch(a[None, :], b[None, :], environment)[0])
+
+    def fk(self, configuration):
+        """<robot>.fk(q) -> list[Sphere] — robot_helper.hh:234-247."""
+        out = self.fk_batch(_f32(configuration, (self._dim,))[None, :])[0]
+        return [Sphere(s[:3], s[3]) for s in out]
+
+    # batched calls --------------------------------------------------------------------------------------------
+    def _env(self, environment):
+        return (environment if environment is not None else Environment()).handle()
+
+    def validate_batch(self, configurations, environment: Environment | None = None):
+        """bool[n] (numpy in -> numpy out; torch CUDA tensor in -> torch.bool CUDA tensor out)."""
+        if _is_torch_cuda(configurations):
+            return self._torch_bits(configurations, None, environment)
+        q = _f32(configurations)
+        if q.ndim != 2 or q.shape[1] != self._dim:
+            raise TypeError(f"expected [n][{self._dim}] configurations")
+        n = q.shape[0]
+        bits = np.zeros((n + 63) // 64, np.uint64)
+        check(lib.vmv_validate_batch_host(self._id, self._env(environment), _fp(q), n,
+                                          bits.ctypes.data_as(_lib.c_u64_p)), "vmv_validate_batch_host")
+        return unpack_bits(bits, n)
+
+    def validate_motion_batch(self, starts, goals, environment: Environment | None = None):
+        if _is_torch_cuda(starts):
+            return self._torch_bits(starts, goals, environment)
+        a, b = _f32(starts), _f32(goals)
+        if a.ndim != 2 or a.shape[1] != self._dim or a.shape != b.shape:
+            raise TypeError(f"expected two [n][{self._dim}] arrays")
+        n = a.shape[0]
+        bits = np.zeros((n + 63) // 64, np.uint64)
+        check(lib.vmv_validate_motion_batch_host(self._id, self._env(environment), _fp(a), _fp(b), n,
+                                                 bits.ctypes.data_as(_lib.c_u64_p)), "vmv_validate_motion_batch_host")
+        return unpack_bits(bits, n)
+
+    def fk_batch(self, configurations):
+        """float32 [n][n_spheres][4] = x y z r."""
+        q = _f32(configurations)
+        if q.ndim != 2 or q.shape[1] != self._dim:
+            raise TypeError(f"expected [n][{self._dim}] configurations")
+        out = np.zeros((q.shape[0], self._ns, 4), np.float32)
+        check(lib.vmv_fk_batch_host(self._id, _fp(q), q.shape[0], _fp(out)), "vmv_fk_batch_host")
+        return out
+
+    # device-resident (torch tensors are only the memory/stream plumbing) ------------------------------------
+    def validate_bits_device(self, q, environment, bits, goals=None):
+        """q (and goals): torch float32 CUDA [n][dim] contiguous; bits: torch int64 CUDA [ceil(n/64)].
+        Launches on torch's current stream; returns nothing (bits is filled in place)."""
+        import torch
+
+        n = q.shape[0]
+        assert q.is_contiguous() and q.dtype == torch.float32 and q.shape[1] == self._dim
+        assert bits.is_contiguous() and bits.dtype == torch.int64 and bits.numel() >= (n + 63) // 64
+        stream = ctypes.c_void_p(torch.cuda.current_stream(q.device).cuda_stream)
+        env = self._env(environment)
+        if goals is None:
+            check(lib.vmv_validate_batch(self._id, env, ctypes.c_void_p(q.data_ptr()), n,
+                                         ctypes.c_void_p(bits.data_ptr()), stream), "vmv_validate_batch")
+        else:
+            assert goals.is_contiguous() and goals.shape == q.shape and goals.dtype == torch.float32
+            check(lib.vmv_validate_motion_batch(self._id, env, ctypes.c_void_p(q.data_ptr()),
+                                                ctypes.c_void_p(goals.data_ptr()), n, ctypes.c_void_p(bits.data_ptr()),
+                                                stream), "vmv_validate_motion_batch")
+
+    def _torch_bits(self, a, b, environment):
+        import torch
+
+        with torch.cuda.device(a.device):
+            a = a.contiguous().float()
+            n = a.shape[0]
+            bits = torch.zeros((n + 63) // 64, dtype=torch.int64, device=a.device)
+            self.validate_bits_device(a, environment, bits, None if b is None else b.contiguous().float())
+            shifts = torch.arange(64, device=a.device, dtype=torch.int64)
+            return (((bits[:, None] >> shifts[None, :]) & 1) != 0).reshape(-1)[:n]
+
+
+for _name in robots():
+    _mod = _Robot(_name)
+    globals()[_name] = _mod
+    sys.modules[_mod.__name__] = _mod
+    __all__.append(_name)

@@ -1,0 +1,588 @@
+// vmv_api.hip — C ABI (include/vamp_mvt_amd.h): environment builder/upload, robot table, dispatch to the
+// per-robot kernel translation units (gen/tu_<robot>.hip).
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (see __graft_entry__.build()).  There is no CPU
+// fallback anywhere in this library: every compute entry point needs a HIP device.
+#include "../../include/vamp_mvt_amd.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "vmv_capt_build.h"
+#include "vmv_common.h"
+
+// ---------------------------------------------------------------------------------------------------------
+// host-side robot table
+// ---------------------------------------------------------------------------------------------------------
+struct vmv_robot_info
+{
+    const char *name;
+    int dimension, n_spheres, resolution;
+    float min_radius, max_radius;
+    float lower[16], span[16], descale[16];
+    const char *end_effector;
+    const char *joint_names[16];
+};
+#include "gen/robots_host.inc"
+
+namespace
+{
+    thread_local std::string g_last_error;
+
+    int hip_fail(hipError_t e, const char *what)
+    {
+        g_last_error = std::string(what) + ": " + hipGetErrorString(e);
+        return (e == hipErrorNoDevice || e == hipErrorInvalidDevice || e == hipErrorInsufficientDriver) ?
+                   VMV_ERR_NO_DEVICE :
+                   VMV_ERR_HIP;
+    }
+#define VMV_HIP(call)                                  \
+    do                                                 \
+    {                                                  \
+        hipError_t e_ = (call);                        \
+        if (e_ != hipSuccess) return hip_fail(e_, #call); \
+    } while (0)
+
+    int require_device()
+    {
+        int n = 0;
+        hipError_t e = hipGetDeviceCount(&n);
+        if (e != hipSuccess || n <= 0)
+        {
+            g_last_error = "no HIP device (this library has no CPU path)";
+            return VMV_ERR_NO_DEVICE;
+        }
+        return VMV_OK;
+    }
+
+    using vmv::kMaxPrimFloats;
+
+    const vmv::RobotLaunchers *const kLaunchers[] = {&vmv::kPandaLaunchers, &vmv::kUr5Launchers, &vmv::kFetchLaunchers,
+                                                     &vmv::kBaxterLaunchers};
+}  // namespace
+
+namespace vmv
+{
+    int hip_status(hipError_t e, const char *what) { return hip_fail(e, what); }
+
+    // uniform configurations inside the joint bounds (bench input generator, counter based)
+    __global__ void fill_uniform_kernel(float *q, size_t total, int dim, uint64_t seed, const float *lower,
+                                        const float *span)
+    {
+        const size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+        if (i >= total) return;
+        uint64_t z = seed + 0x9e3779b97f4a7c15ull * (uint64_t) (i + 1);
+        z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+        z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+        z = z ^ (z >> 31);
+        const float u = (float) (z >> 40) * (1.0f / 16777216.0f);
+        const int j = (int) (i % (size_t) dim);
+        q[i] = lower[j] + span[j] * u;
+    }
+}  // namespace vmv
+
+// ---------------------------------------------------------------------------------------------------------
+// environment (host builder + device image)
+// ---------------------------------------------------------------------------------------------------------
+struct vmv_env
+{
+    struct Sphere
+    {
+        float x, y, z, r, min_d;
+    };
+    struct Cuboid
+    {
+        float p[15];
+        float min_d;
+    };
+    struct Capsule
+    {
+        float p[8];
+        float min_d;
+    };
+    std::vector<Sphere> spheres;
+    std::vector<Capsule> capsules, z_capsules;
+    std::vector<Cuboid> cuboids, z_cuboids;
+    std::vector<vmv::CaptArrays> capts;
+
+    bool finalized = false;
+    int device = -1;
+    vmv::EnvLaunch launch{};  // host + device copies of the kernel-side description
+    std::vector<void *> allocations;
+};
+
+namespace
+{
+    float dot3h(float ax, float ay, float az, float bx, float by, float bz) { return (ax * bx) + (ay * by) + (az * bz); }
+    float clamp_scalar(float v, float lo, float hi) { return std::max(std::min(v, hi), lo); }  // collision/math.hh:47-51
+
+    // collision/shapes.hh:52-67
+    float cuboid_min_distance(const float *p)
+    {
+        const float x = p[0], y = p[1], z = p[2];
+        const float d1 = dot3h(-x, -y, -z, p[3], p[4], p[5]);
+        const float d2 = dot3h(-x, -y, -z, p[6], p[7], p[8]);
+        const float d3 = dot3h(-x, -y, -z, p[9], p[10], p[11]);
+        const float v1 = clamp_scalar(d1, -p[12], p[12]);
+        const float v2 = clamp_scalar(d2, -p[13], p[13]);
+        const float v3 = clamp_scalar(d3, -p[14], p[14]);
+        const float xn = x + p[3] * v1 + p[6] * v2 + p[9] * v3;
+        const float yn = y + p[4] * v1 + p[7] * v2 + p[10] * v3;
+        const float zn = z + p[5] * v1 + p[8] * v2 + p[11] * v3;
+        return std::sqrt(xn * xn + yn * yn + zn * zn);
+    }
+
+    // collision/shapes.hh:165-189
+    float capsule_min_distance(const float *p)
+    {
+        const float x1 = p[0], y1 = p[1], z1 = p[2], xv = p[3], yv = p[4], zv = p[5], r = p[6], rdv = p[7];
+        const float t = clamp_scalar(dot3h(-x1, -y1, -z1, xv, yv, zv) * rdv, 0.F, 1.F);
+        const float xp = x1 + xv * t, yp = y1 + yv * t, zp = z1 + zv * t;
+        float xo = -xp, yo = -yp, zo = -zp;
+        const float ol = std::sqrt(dot3h(xo, yo, zo, xo, yo, zo));
+        xo = xo / ol;
+        yo = yo / ol;
+        zo = zo / ol;
+        const float ro = clamp_scalar(ol, 0.F, r);
+        const float xn = xp + ro * xo, yn = yp + ro * yo, zn = zp + ro * zo;
+        return std::sqrt(xn * xn + yn * yn + zn * zn);
+    }
+
+    template <typename T>
+    void sort_by_min_distance(std::vector<T> &v)
+    {
+        std::stable_sort(v.begin(), v.end(), [](const T &a, const T &b) { return a.min_d < b.min_d; });
+    }
+
+    template <typename T>
+    int upload(vmv_env *env, const std::vector<T> &host, const T **dev_ptr)
+    {
+        void *d = nullptr;
+        const size_t bytes = std::max<size_t>(host.size() * sizeof(T), 16);
+        VMV_HIP(hipMalloc(&d, bytes));
+        env->allocations.push_back(d);
+        if (!host.empty()) VMV_HIP(hipMemcpy(d, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice));
+        *dev_ptr = static_cast<const T *>(d);
+        return VMV_OK;
+    }
+}  // namespace
+
+extern "C"
+{
+    const char *vmv_status_string(int status)
+    {
+        switch (status)
+        {
+            case VMV_OK: return "ok";
+            case VMV_ERR_INVALID_ARGUMENT: return "invalid argument";
+            case VMV_ERR_NO_DEVICE: return "no HIP device";
+            case VMV_ERR_HIP: return "HIP runtime error";
+            case VMV_ERR_CAPACITY: return "environment exceeds on-chip staging capacity";
+            case VMV_ERR_NOT_FINALIZED: return "environment not finalized";
+            case VMV_ERR_UNKNOWN_ROBOT: return "unknown robot";
+            case VMV_ERR_FINALIZED: return "environment already finalized";
+            default: return "unknown status";
+        }
+    }
+    int vmv_abi_version(void) { return 1; }
+    const char *vmv_last_error(void) { return g_last_error.c_str(); }
+
+    int vmv_device_count(int *count)
+    {
+        if (!count) return VMV_ERR_INVALID_ARGUMENT;
+        *count = 0;
+        hipError_t e = hipGetDeviceCount(count);
+        if (e != hipSuccess)
+        {
+            *count = 0;
+            return hip_fail(e, "hipGetDeviceCount");
+        }
+        return VMV_OK;
+    }
+    int vmv_set_device(int device)
+    {
+        VMV_HIP(hipSetDevice(device));
+        return VMV_OK;
+    }
+
+    // ---- robots ----
+    int vmv_num_robots(void) { return kNumRobots; }
+    static bool robot_ok(int r) { return r >= 0 && r < kNumRobots; }
+    const char *vmv_robot_name(int r) { return robot_ok(r) ? kRobots[r].name : nullptr; }
+    int vmv_robot_id(const char *name)
+    {
+        if (!name) return -1;
+        for (int i = 0; i < kNumRobots; ++i)
+            if (std::strcmp(kRobots[i].name, name) == 0) return i;
+        return -1;
+    }
+    int vmv_robot_dimension(int r) { return robot_ok(r) ? kRobots[r].dimension : -1; }
+    int vmv_robot_n_spheres(int r) { return robot_ok(r) ? kRobots[r].n_spheres : -1; }
+    int vmv_robot_resolution(int r) { return robot_ok(r) ? kRobots[r].resolution : -1; }
+    int vmv_robot_min_max_radii(int r, float *mn, float *mx)
+    {
+        if (!robot_ok(r)) return VMV_ERR_UNKNOWN_ROBOT;
+        if (mn) *mn = kRobots[r].min_radius;
+        if (mx) *mx = kRobots[r].max_radius;
+        return VMV_OK;
+    }
+    int vmv_robot_bounds(int r, float *lower, float *span, float *descale)
+    {
+        if (!robot_ok(r)) return VMV_ERR_UNKNOWN_ROBOT;
+        const size_t b = sizeof(float) * (size_t) kRobots[r].dimension;
+        if (lower) std::memcpy(lower, kRobots[r].lower, b);
+        if (span) std::memcpy(span, kRobots[r].span, b);
+        if (descale) std::memcpy(descale, kRobots[r].descale, b);
+        return VMV_OK;
+    }
+    const char *vmv_robot_joint_name(int r, int j)
+    {
+        return (robot_ok(r) && j >= 0 && j < kRobots[r].dimension) ? kRobots[r].joint_names[j] : nullptr;
+    }
+    const char *vmv_robot_end_effector(int r) { return robot_ok(r) ? kRobots[r].end_effector : nullptr; }
+
+    // ---- environment ----
+    int vmv_env_create(vmv_env **out)
+    {
+        if (!out) return VMV_ERR_INVALID_ARGUMENT;
+        *out = new (std::nothrow) vmv_env();
+        return *out ? VMV_OK : VMV_ERR_INVALID_ARGUMENT;
+    }
+    int vmv_env_destroy(vmv_env *env)
+    {
+        if (!env) return VMV_OK;
+        for (void *p : env->allocations) (void) hipFree(p);
+        delete env;
+        return VMV_OK;
+    }
+#define VMV_MUTABLE(env)                                  \
+    if (!(env)) return VMV_ERR_INVALID_ARGUMENT;          \
+    if ((env)->finalized) return VMV_ERR_FINALIZED;
+
+    int vmv_env_add_sphere(vmv_env *env, float x, float y, float z, float r)
+    {
+        VMV_MUTABLE(env)
+        // collision/shapes.hh:236-239
+        env->spheres.push_back({x, y, z, r, std::sqrt(x * x + y * y + z * z) - r});
+        return VMV_OK;
+    }
+    int vmv_env_add_cuboid(vmv_env *env, const float *p)
+    {
+        VMV_MUTABLE(env)
+        if (!p) return VMV_ERR_INVALID_ARGUMENT;
+        vmv_env::Cuboid c;
+        std::memcpy(c.p, p, sizeof(c.p));
+        c.min_d = cuboid_min_distance(p);
+        (p[11] == 1.0f ? env->z_cuboids : env->cuboids).push_back(c);  // environment.cc:123-130
+        return VMV_OK;
+    }
+    int vmv_env_add_capsule(vmv_env *env, const float *p)
+    {
+        VMV_MUTABLE(env)
+        if (!p) return VMV_ERR_INVALID_ARGUMENT;
+        vmv_env::Capsule c;
+        std::memcpy(c.p, p, sizeof(c.p));
+        c.min_d = capsule_min_distance(p);
+        ((p[3] == 0.0f && p[4] == 0.0f) ? env->z_capsules : env->capsules).push_back(c);  // environment.cc:137-144
+        return VMV_OK;
+    }
+    int vmv_env_add_capt_pointcloud(vmv_env *env, const float *pts, size_t n, float r_min, float r_max, float r_point,
+                                    uint64_t *build_ns)
+    {
+        VMV_MUTABLE(env)
+        if (!pts || n < 2) return VMV_ERR_INVALID_ARGUMENT;
+        if (env->capts.size() >= (size_t) vmv::kMaxCapt) return VMV_ERR_CAPACITY;
+        const auto t0 = std::chrono::steady_clock::now();
+        vmv::CaptArrays arrays;
+        if (!vmv::build_capt(pts, n, r_min, r_max, r_point, arrays)) return VMV_ERR_INVALID_ARGUMENT;
+        env->capts.push_back(std::move(arrays));
+        if (build_ns)
+            *build_ns = (uint64_t) std::chrono::duration_cast<std::chrono::nanoseconds>(
+                            std::chrono::steady_clock::now() - t0)
+                            .count();
+        return VMV_OK;
+    }
+
+    int vmv_env_finalize(vmv_env *env)
+    {
+        VMV_MUTABLE(env)
+        int rc = require_device();
+        if (rc != VMV_OK) return rc;
+        sort_by_min_distance(env->spheres);
+        sort_by_min_distance(env->capsules);
+        sort_by_min_distance(env->z_capsules);
+        sort_by_min_distance(env->cuboids);
+        sort_by_min_distance(env->z_cuboids);
+
+        // pack the LDS primitive block (record layouts: vmv_device.h)
+        std::vector<float> block;
+        vmv::EnvDev &D = env->launch.host;
+        D = vmv::EnvDev{};
+        D.n_sphere = (uint32_t) env->spheres.size();
+        D.off_sphere = (uint32_t) block.size();
+        for (const auto &s : env->spheres) block.insert(block.end(), {s.x, s.y, s.z, s.r, s.min_d, 0.f, 0.f, 0.f});
+        D.n_capsule = (uint32_t) env->capsules.size();
+        D.off_capsule = (uint32_t) block.size();
+        for (const auto &c : env->capsules)
+            block.insert(block.end(),
+                         {c.p[0], c.p[1], c.p[2], c.p[3], c.p[4], c.p[5], c.p[6], c.p[7], c.min_d, 0.f, 0.f, 0.f});
+        D.n_zcapsule = (uint32_t) env->z_capsules.size();
+        D.off_zcapsule = (uint32_t) block.size();
+        for (const auto &c : env->z_capsules)
+            block.insert(block.end(), {c.p[0], c.p[1], c.p[2], c.p[5], c.p[6], c.p[7], c.min_d, 0.f});
+        D.n_cuboid = (uint32_t) env->cuboids.size();
+        D.off_cuboid = (uint32_t) block.size();
+        for (const auto &c : env->cuboids)
+        {
+            block.insert(block.end(), c.p, c.p + 15);
+            block.push_back(c.min_d);
+        }
+        D.n_zcuboid = (uint32_t) env->z_cuboids.size();
+        D.off_zcuboid = (uint32_t) block.size();
+        for (const auto &c : env->z_cuboids)
+            block.insert(block.end(), {c.p[0], c.p[1], c.p[2], c.p[3], c.p[4], c.p[6], c.p[7], c.p[12], c.p[13],
+                                       c.p[14], c.min_d, 0.f});
+        while (block.size() % 4) block.push_back(0.f);
+        if (block.size() > kMaxPrimFloats)
+        {
+            g_last_error = "more primitive records than the LDS staging budget (48 KiB)";
+            return VMV_ERR_CAPACITY;
+        }
+        D.n_floats = (uint32_t) block.size();
+        VMV_HIP(hipGetDevice(&env->device));
+        rc = upload(env, block, &D.prims);
+        if (rc != VMV_OK) return rc;
+
+        D.n_capt = (uint32_t) env->capts.size();
+        for (size_t i = 0; i < env->capts.size(); ++i)
+        {
+            const vmv::CaptArrays &a = env->capts[i];
+            vmv::CaptDev &c = D.capt[i];
+            if ((rc = upload(env, a.tests, &c.tests)) != VMV_OK) return rc;
+            if ((rc = upload(env, a.aff_starts, &c.aff_starts)) != VMV_OK) return rc;
+            if ((rc = upload(env, a.aabbs, &c.aabbs)) != VMV_OK) return rc;
+            if ((rc = upload(env, a.aff[0], &c.aff_x)) != VMV_OK) return rc;
+            if ((rc = upload(env, a.aff[1], &c.aff_y)) != VMV_OK) return rc;
+            if ((rc = upload(env, a.aff[2], &c.aff_z)) != VMV_OK) return rc;
+            std::memcpy(c.aabb_top, a.aabb_top, sizeof(c.aabb_top));
+            c.r_point = a.r_point;
+            c.nlog2 = a.nlog2;
+            c.n_tests = (uint32_t) a.tests.size();
+        }
+        D.capt0_n_tests = D.n_capt ? (uint32_t) env->capts[0].tests.size() : 0u;
+        {
+            std::vector<vmv::EnvDev> one(1, D);
+            if ((rc = upload(env, one, &env->launch.d_env)) != VMV_OK) return rc;
+        }
+        env->finalized = true;
+        return VMV_OK;
+    }
+
+    int vmv_env_counts(const vmv_env *env, size_t *c)
+    {
+        if (!env || !c) return VMV_ERR_INVALID_ARGUMENT;
+        c[0] = env->spheres.size();
+        c[1] = env->capsules.size();
+        c[2] = env->z_capsules.size();
+        c[3] = env->cuboids.size();
+        c[4] = env->z_cuboids.size();
+        c[5] = env->capts.size();
+        return VMV_OK;
+    }
+    int vmv_env_get_spheres(const vmv_env *env, float *out, size_t cap, size_t *n)
+    {
+        if (!env || !n) return VMV_ERR_INVALID_ARGUMENT;
+        *n = env->spheres.size();
+        if (out)
+            for (size_t i = 0; i < std::min(cap, *n); ++i) std::memcpy(out + 5 * i, &env->spheres[i], 5 * sizeof(float));
+        return VMV_OK;
+    }
+    int vmv_env_get_cuboids(const vmv_env *env, int z, float *out, size_t cap, size_t *n)
+    {
+        if (!env || !n) return VMV_ERR_INVALID_ARGUMENT;
+        const auto &v = z ? env->z_cuboids : env->cuboids;
+        *n = v.size();
+        if (out)
+            for (size_t i = 0; i < std::min(cap, *n); ++i) std::memcpy(out + 16 * i, &v[i], 16 * sizeof(float));
+        return VMV_OK;
+    }
+    int vmv_env_get_capsules(const vmv_env *env, int z, float *out, size_t cap, size_t *n)
+    {
+        if (!env || !n) return VMV_ERR_INVALID_ARGUMENT;
+        const auto &v = z ? env->z_capsules : env->capsules;
+        *n = v.size();
+        if (out)
+            for (size_t i = 0; i < std::min(cap, *n); ++i) std::memcpy(out + 9 * i, &v[i], 9 * sizeof(float));
+        return VMV_OK;
+    }
+    int vmv_env_capt_sizes(const vmv_env *env, size_t index, uint32_t *nlog2, uint32_t *n_aff)
+    {
+        if (!env || index >= env->capts.size()) return VMV_ERR_INVALID_ARGUMENT;
+        if (nlog2) *nlog2 = env->capts[index].nlog2;
+        if (n_aff) *n_aff = env->capts[index].n_aff_vectors();
+        return VMV_OK;
+    }
+    int vmv_env_capt_arrays(const vmv_env *env, size_t index, float *tests, uint32_t *aff_starts, float *aabbs,
+                            float *ax, float *ay, float *az, float *top)
+    {
+        if (!env || index >= env->capts.size()) return VMV_ERR_INVALID_ARGUMENT;
+        const vmv::CaptArrays &a = env->capts[index];
+        if (tests) std::memcpy(tests, a.tests.data(), a.tests.size() * 4);
+        if (aff_starts) std::memcpy(aff_starts, a.aff_starts.data(), a.aff_starts.size() * 4);
+        if (aabbs) std::memcpy(aabbs, a.aabbs.data(), a.aabbs.size() * 4);
+        if (ax) std::memcpy(ax, a.aff[0].data(), a.aff[0].size() * 4);
+        if (ay) std::memcpy(ay, a.aff[1].data(), a.aff[1].size() * 4);
+        if (az) std::memcpy(az, a.aff[2].data(), a.aff[2].size() * 4);
+        if (top) std::memcpy(top, a.aabb_top, sizeof(a.aabb_top));
+        return VMV_OK;
+    }
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------
+// batched entry points
+// ---------------------------------------------------------------------------------------------------------
+extern "C"
+{
+    int vmv_validate_batch(int robot, const vmv_env *env, const float *d_q, size_t n, uint64_t *d_bits, void *stream)
+    {
+        if (!robot_ok(robot)) return VMV_ERR_UNKNOWN_ROBOT;
+        if (!env || !d_q || !d_bits) return VMV_ERR_INVALID_ARGUMENT;
+        if (!env->finalized) return VMV_ERR_NOT_FINALIZED;
+        if (n == 0) return VMV_OK;
+        return kLaunchers[robot]->validate(env->launch, d_q, n, d_bits, static_cast<hipStream_t>(stream));
+    }
+
+    int vmv_validate_motion_batch(int robot, const vmv_env *env, const float *d_a, const float *d_b, size_t n,
+                                  uint64_t *d_bits, void *stream)
+    {
+        if (!robot_ok(robot)) return VMV_ERR_UNKNOWN_ROBOT;
+        if (!env || !d_a || !d_b || !d_bits) return VMV_ERR_INVALID_ARGUMENT;
+        if (!env->finalized) return VMV_ERR_NOT_FINALIZED;
+        if (n == 0) return VMV_OK;
+        return kLaunchers[robot]->validate_motion(env->launch, d_a, d_b, n, d_bits, static_cast<hipStream_t>(stream));
+    }
+
+    int vmv_fk_batch(int robot, const float *d_q, size_t n, float *d_out, void *stream)
+    {
+        if (!robot_ok(robot)) return VMV_ERR_UNKNOWN_ROBOT;
+        if (!d_q || !d_out) return VMV_ERR_INVALID_ARGUMENT;
+        if (n == 0) return VMV_OK;
+        return kLaunchers[robot]->fk(d_q, n, d_out, static_cast<hipStream_t>(stream));
+    }
+
+    // ---- host-buffer variants ----
+    int vmv_fk_batch_host(int robot, const float *q, size_t n, float *out)
+    {
+        if (!robot_ok(robot)) return VMV_ERR_UNKNOWN_ROBOT;
+        if (!q || !out) return VMV_ERR_INVALID_ARGUMENT;
+        if (n == 0) return VMV_OK;
+        int rc = require_device();
+        if (rc != VMV_OK) return rc;
+        const size_t qb = n * (size_t) kRobots[robot].dimension * 4, ob = n * (size_t) kRobots[robot].n_spheres * 16;
+        float *dq = nullptr, *dout = nullptr;
+        VMV_HIP(hipMalloc((void **) &dq, qb));
+        if (hipMalloc((void **) &dout, ob) != hipSuccess)
+        {
+            (void) hipFree(dq);
+            return VMV_ERR_HIP;
+        }
+        rc = VMV_OK;
+        if (hipMemcpy(dq, q, qb, hipMemcpyHostToDevice) != hipSuccess) rc = VMV_ERR_HIP;
+        if (rc == VMV_OK) rc = vmv_fk_batch(robot, dq, n, dout, nullptr);
+        if (rc == VMV_OK && hipMemcpy(out, dout, ob, hipMemcpyDeviceToHost) != hipSuccess) rc = VMV_ERR_HIP;
+        (void) hipFree(dq);
+        (void) hipFree(dout);
+        return rc;
+    }
+
+    static int validate_host_common(int robot, const vmv_env *env, const float *a, const float *b, size_t n,
+                                    uint64_t *bits)
+    {
+        if (!robot_ok(robot)) return VMV_ERR_UNKNOWN_ROBOT;
+        if (!a || !bits) return VMV_ERR_INVALID_ARGUMENT;
+        if (n == 0) return VMV_OK;
+        int rc = require_device();
+        if (rc != VMV_OK) return rc;
+        const size_t qb = n * (size_t) kRobots[robot].dimension * 4, wb = ((n + 63) / 64) * 8;
+        float *da = nullptr, *db = nullptr;
+        uint64_t *dbits = nullptr;
+        VMV_HIP(hipMalloc((void **) &da, qb));
+        rc = VMV_OK;
+        if (b && hipMalloc((void **) &db, qb) != hipSuccess) rc = VMV_ERR_HIP;
+        if (rc == VMV_OK && hipMalloc((void **) &dbits, wb) != hipSuccess) rc = VMV_ERR_HIP;
+        if (rc == VMV_OK && hipMemcpy(da, a, qb, hipMemcpyHostToDevice) != hipSuccess) rc = VMV_ERR_HIP;
+        if (rc == VMV_OK && b && hipMemcpy(db, b, qb, hipMemcpyHostToDevice) != hipSuccess) rc = VMV_ERR_HIP;
+        if (rc == VMV_OK)
+            rc = b ? vmv_validate_motion_batch(robot, env, da, db, n, dbits, nullptr) :
+                     vmv_validate_batch(robot, env, da, n, dbits, nullptr);
+        if (rc == VMV_OK && hipMemcpy(bits, dbits, wb, hipMemcpyDeviceToHost) != hipSuccess) rc = VMV_ERR_HIP;
+        (void) hipFree(da);
+        (void) hipFree(db);
+        (void) hipFree(dbits);
+        return rc;
+    }
+    int vmv_validate_batch_host(int robot, const vmv_env *env, const float *q, size_t n, uint64_t *bits)
+    {
+        return validate_host_common(robot, env, q, nullptr, n, bits);
+    }
+    int vmv_validate_motion_batch_host(int robot, const vmv_env *env, const float *a, const float *b, size_t n,
+                                       uint64_t *bits)
+    {
+        if (!b) return VMV_ERR_INVALID_ARGUMENT;
+        return validate_host_common(robot, env, a, b, n, bits);
+    }
+
+    // ---- measurement support ----
+    int vmv_time_validate_batch(int robot, const vmv_env *env, const float *d_q, size_t n, uint64_t *d_bits, int iters,
+                                void *stream, float *avg_ms)
+    {
+        if (!avg_ms || iters < 1) return VMV_ERR_INVALID_ARGUMENT;
+        hipStream_t s = static_cast<hipStream_t>(stream);
+        hipEvent_t e0, e1;
+        VMV_HIP(hipEventCreate(&e0));
+        VMV_HIP(hipEventCreate(&e1));
+        VMV_HIP(hipEventRecord(e0, s));
+        int rc = VMV_OK;
+        for (int i = 0; i < iters && rc == VMV_OK; ++i) rc = vmv_validate_batch(robot, env, d_q, n, d_bits, stream);
+        VMV_HIP(hipEventRecord(e1, s));
+        VMV_HIP(hipEventSynchronize(e1));
+        float ms = 0.f;
+        VMV_HIP(hipEventElapsedTime(&ms, e0, e1));
+        (void) hipEventDestroy(e0);
+        (void) hipEventDestroy(e1);
+        *avg_ms = ms / (float) iters;
+        return rc;
+    }
+
+    int vmv_fill_uniform_configs(int robot, float *d_q, size_t n, uint64_t seed, void *stream)
+    {
+        if (!robot_ok(robot)) return VMV_ERR_UNKNOWN_ROBOT;
+        if (!d_q) return VMV_ERR_INVALID_ARGUMENT;
+        const int dim = kRobots[robot].dimension;
+        float *d_bounds = nullptr;
+        VMV_HIP(hipMalloc((void **) &d_bounds, 32 * sizeof(float)));
+        VMV_HIP(hipMemcpy(d_bounds, kRobots[robot].lower, 16 * sizeof(float), hipMemcpyHostToDevice));
+        VMV_HIP(hipMemcpy(d_bounds + 16, kRobots[robot].span, 16 * sizeof(float), hipMemcpyHostToDevice));
+        const size_t total = n * (size_t) dim;
+        hipLaunchKernelGGL(vmv::fill_uniform_kernel, dim3((unsigned) ((total + 255) / 256)), dim3(256), 0,
+                           static_cast<hipStream_t>(stream), d_q, total, dim, seed, d_bounds, d_bounds + 16);
+        VMV_HIP(hipGetLastError());
+        VMV_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+        (void) hipFree(d_bounds);
+        return VMV_OK;
+    }
+
+    const char *vmv_kernel_name(int robot, const char *entry_point)
+    {
+        static thread_local std::string name;
+        if (!robot_ok(robot) || !entry_point) return nullptr;
+        name = std::string("vmv::") + kRobots[robot].name + "::" + entry_point + "_kernel";
+        return name.c_str();
+    }
+}  // extern "C"

@@ -1,0 +1,36 @@
+// vmv_common.h — declarations shared by the API translation unit and the per-robot kernel translation units.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "vmv_device.h"
+
+namespace vmv
+{
+    constexpr int kBlock = 256;  // 4 waves per workgroup; each wave owns one LDS slab
+    constexpr int kWavesPerBlock = kBlock / kWave;
+    constexpr uint32_t kMaxLdsBytes = 160u * 1024u;   // gfx950 LDS per CU / max per workgroup
+    constexpr uint32_t kMaxPrimFloats = 12u * 1024u;  // 48 KiB of primitive records
+
+    // what a launcher needs to know about a finalized environment
+    struct EnvLaunch
+    {
+        const EnvDev *d_env;  // device copy
+        EnvDev host;          // host copy (sizes)
+    };
+
+    // status codes are the VMV_* values of include/vamp_mvt_amd.h
+    struct RobotLaunchers
+    {
+        int (*validate)(const EnvLaunch &, const float *d_q, size_t n, uint64_t *d_bits, hipStream_t);
+        int (*validate_motion)(const EnvLaunch &, const float *d_a, const float *d_b, size_t n, uint64_t *d_bits,
+                               hipStream_t);
+        int (*fk)(const float *d_q, size_t n, float *d_out, hipStream_t);
+    };
+
+    extern const RobotLaunchers kPandaLaunchers, kUr5Launchers, kFetchLaunchers, kBaxterLaunchers;
+
+    int hip_status(hipError_t e, const char *what);  // records vmv_last_error(), maps to VMV_ERR_*
+}  // namespace vmv

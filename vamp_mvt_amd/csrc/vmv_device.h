@@ -1,0 +1,379 @@
+// vmv_device.h — gfx950 device primitives for the motion-validation hot path.
+//
+// One wavefront lane = one rake lane (one configuration).  All arithmetic is
+// IEEE fp32 with one rounding per written operation: this translation unit is
+// compiled with -ffp-contract=off and without fast-math, so that the per-lane
+// results are bit-identical to the reference's AVX2 lanes (SURVEY.md §2 table of
+// SIMD primitives).  Reference citations are file:line under
+// /root/reference/src/impl/vamp/.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace vmv
+{
+    constexpr int kWave = 64;  // gfx950 wavefront
+
+    // explicit LDS address space: pointers that cross a (non-inlined) call keep ds_read/ds_write addressing
+    using lds_float = __attribute__((address_space(3))) float;
+    using lds_ptr = lds_float *;
+    using lds_cptr = const lds_float *;
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    __device__ __forceinline__ v4f lds_load4(lds_cptr p)
+    {
+        return *(const __attribute__((address_space(3))) v4f *) p;  // 16-byte aligned record -> ds_read_b128
+    }
+
+    // ------------------------------------------------------------------------
+    // L0: value-type semantics (vector/avx.hh, vector/interface.hh), per lane
+    // ------------------------------------------------------------------------
+    __device__ __forceinline__ uint32_t f2u(float f) { return __float_as_uint(f); }
+    __device__ __forceinline__ float u2f(uint32_t u) { return __uint_as_float(u); }
+    // `not v.test_zero()` for one lane: the sign bit (interface.hh:257-277, avx.hh:385-389)
+    __device__ __forceinline__ bool neg(float f) { return (f2u(f) >> 31) != 0u; }
+    // _mm256_max_ps / _mm256_min_ps operand order and NaN rule (avx.hh:429-439)
+    __device__ __forceinline__ float x86_max(float a, float b) { return a > b ? a : b; }
+    __device__ __forceinline__ float x86_min(float a, float b) { return a < b ? a : b; }
+    __device__ __forceinline__ float vclamp(float v, float lo, float hi) { return x86_min(x86_max(v, lo), hi); }
+    __device__ __forceinline__ float vabs(float v) { return u2f(f2u(v) & 0x7fffffffu); }
+
+    // vector/avx.hh:455-548: cephes sine.  cvtps_epi32 is round-to-nearest-even = v_rndne + v_cvt.
+    __device__ __forceinline__ float vsin(float x)
+    {
+        uint32_t sign_bit = f2u(x) & 0x80000000u;
+        x = vabs(x);
+        float y = x * 1.27323954473516f;
+        int32_t j = (y < 2147483648.0f) ? __float2int_rn(y) : (int32_t) 0x80000000;
+        j = (int32_t) (((uint32_t) j + 1u) & ~1u);
+        y = (float) j;
+        const uint32_t swap_sign = ((uint32_t) j & 4u) << 29;
+        const bool poly_sin = (((uint32_t) j & 2u) == 0u);
+        sign_bit ^= swap_sign;
+        const float xmm1 = y * -0.78515625f;
+        const float xmm2 = y * -2.4187564849853515625e-4f;
+        const float xmm3 = y * -3.77489497744594108e-8f;
+        x = x + xmm1;
+        x = x + xmm2;
+        x = x + xmm3;
+        const float z = x * x;
+        float yc = 2.443315711809948E-005f;
+        yc = yc * z;
+        yc = yc + -1.388731625493765E-003f;
+        yc = yc * z;
+        yc = yc + 4.166664568298827E-002f;
+        yc = yc * z;
+        yc = yc * z;
+        const float tmp = z * 0.5f;
+        yc = yc - tmp;
+        yc = yc + 1.0f;
+        float y2 = -1.9515295891E-4f;
+        y2 = y2 * z;
+        y2 = y2 + 8.3321608736E-3f;
+        y2 = y2 * z;
+        y2 = y2 + -1.6666654611E-1f;
+        y2 = y2 * z;
+        y2 = y2 * x;
+        y2 = y2 + x;
+        // and/andnot select followed by an add of +0.0f (turns a selected -0.0f into +0.0f)
+        const float sel = (poly_sin ? y2 : yc) + 0.0f;
+        return u2f(f2u(sel) ^ sign_bit);
+    }
+
+    // vector/interface.hh:447-458
+    __device__ __forceinline__ float vcos(float x)
+    {
+        const float PI = 3.14159265359f;
+        const float v_sq = x + (float) (PI / 2.);
+        const float sub = (v_sq >= PI) ? (float) (2 * PI) : 0.0f;
+        return vsin(v_sq - sub);
+    }
+
+    // ------------------------------------------------------------------------
+    // wave / rake-group helpers.  G = 1: every lane is its own rake (one configuration replicated over
+    // the reference's 8 lanes).  G = 8: lanes 8k..8k+7 form one reference rake (planning/validate.hh).
+    // ------------------------------------------------------------------------
+    __device__ __forceinline__ bool wave_any(bool p) { return __ballot(p) != 0ull; }
+
+    template <int G>
+    __device__ __forceinline__ bool group_any(bool p)
+    {
+        if constexpr (G == 1)
+        {
+            return p;
+        }
+        else
+        {
+            const uint64_t b = __ballot(p);
+            const unsigned lane = __lane_id();
+            return ((b >> (lane & ~7u)) & 0xffull) != 0ull;
+        }
+    }
+
+    template <int G>
+    __device__ __forceinline__ float group_max(float v)
+    {
+        if constexpr (G == 1)
+        {
+            return v;
+        }
+        else
+        {
+            // butterfly over the 8 lanes of the rake (xor 1, 2, 4)
+            v = fmaxf(v, __shfl_xor(v, 1));
+            v = fmaxf(v, __shfl_xor(v, 2));
+            v = fmaxf(v, __shfl_xor(v, 4));
+            return v;
+        }
+    }
+
+    // ------------------------------------------------------------------------
+    // L1a: environment as the kernels see it.  Primitive records live in LDS (staged once per workgroup);
+    // CAPT arrays stay in HBM/L2 except the split planes, which are staged in LDS when they fit.
+    // Record layouts (floats), every list sorted by min_distance (collision/environment.hh:46-72):
+    //   sphere     [8]  x y z r | min_d 0 0 0
+    //   capsule    [12] x1 y1 z1 xv | yv zv r rdv | min_d 0 0 0
+    //   z_capsule  [8]  x1 y1 z1 zv | r rdv min_d 0
+    //   cuboid     [16] x y z a1x | a1y a1z a2x a2y | a2z a3x a3y a3z | r1 r2 r3 min_d
+    //   z_cuboid   [12] x y z a1x | a1y a2x a2y r1 | r2 r3 min_d 0
+    // ------------------------------------------------------------------------
+    constexpr int kSphereRec = 8, kCapsuleRec = 12, kZCapsuleRec = 8, kCuboidRec = 16, kZCuboidRec = 12;
+
+    struct CaptDev
+    {
+        const float *tests;          // 2^nlog2 - 1
+        const uint32_t *aff_starts;  // 2^nlog2 + 1
+        const float *aabbs;          // 2^nlog2 * 6
+        const float *aff_x, *aff_y, *aff_z;  // n_aff * 8
+        float aabb_top[6];
+        float r_point;
+        uint32_t nlog2, n_tests;
+    };
+
+    constexpr int kMaxCapt = 4;
+
+    struct EnvDev  // kernel argument (by value)
+    {
+        const float *prims;  // HBM image of the LDS primitive block
+        uint32_t n_floats;   // size of that block
+        uint32_t n_sphere, n_capsule, n_zcapsule, n_cuboid, n_zcuboid;
+        uint32_t off_sphere, off_capsule, off_zcapsule, off_cuboid, off_zcuboid;  // float offsets in the block
+        uint32_t n_capt;
+        uint32_t capt0_n_tests;  // size of capt[0].tests (candidate for LDS staging behind the primitive block)
+        CaptDev capt[kMaxCapt];
+    };
+
+    struct EnvView
+    {
+        const EnvDev *dev;         // device memory (uniform loads)
+        lds_cptr lds;              // primitive block in LDS
+        const float *capt0_tests;  // split planes of point cloud 0: LDS copy when staged, else dev->capt[0].tests
+    };
+
+    // collision/math.hh:10-42
+    __device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, float by, float bz)
+    {
+        return (ax * bx) + (ay * by) + (az * bz);
+    }
+    __device__ __forceinline__ float sql2_3(float ax, float ay, float az, float bx, float by, float bz)
+    {
+        const float xs = ax - bx, ys = ay - by, zs = az - bz;
+        return dot3(xs, ys, zs, xs, ys, zs);
+    }
+    // collision/sphere_sphere.hh:9-23
+    __device__ __forceinline__ float
+    sphere_sphere_sql2(float ax, float ay, float az, float ar, float bx, float by, float bz, float br)
+    {
+        const float sum = sql2_3(ax, ay, az, bx, by, bz);
+        const float rs = ar + br;
+        return sum - rs * rs;
+    }
+
+    // CAPT::collides_simd (collision/capt.hh:428-512), one lane.  The reference's `inbounds.none()` early
+    // returns do not change any lane's answer, so a lane's result is independent of its rake neighbours.
+    __device__ __forceinline__ bool
+    capt_collides(const CaptDev &c, const float *tests, float x, float y, float z, float r, bool active)
+    {
+        bool inb = active;
+        inb = inb && (x + r >= c.aabb_top[0]) && (x - r <= c.aabb_top[3]);
+        inb = inb && (y + r >= c.aabb_top[1]) && (y - r <= c.aabb_top[4]);
+        inb = inb && (z + r >= c.aabb_top[2]) && (z - r <= c.aabb_top[5]);
+        if (!wave_any(inb)) return false;
+
+        uint32_t idx = (uint32_t) (x >= tests[0]) + 1u;
+        uint32_t k = 1;
+        for (uint32_t i = 1; i < c.nlog2; ++i)
+        {
+            const float ck = (k == 0) ? x : (k == 1) ? y : z;
+            idx = (idx << 1) + (uint32_t) (ck >= tests[idx]) + 1u;
+            k = (k == 2) ? 0 : k + 1;
+        }
+        const uint32_t zi = idx - c.n_tests;
+        const float rr = r + c.r_point;
+        const float rc_sq = rr * rr;
+        const float *bb = c.aabbs + 6 * (size_t) zi;
+        const float d0 = x - vclamp(x, bb[0], bb[3]);
+        const float d1 = y - vclamp(y, bb[1], bb[4]);
+        const float d2 = z - vclamp(z, bb[2], bb[5]);
+        const float distsq = d0 * d0 + d1 * d1 + d2 * d2;
+        inb = inb && (distsq <= rc_sq);
+        if (!wave_any(inb)) return false;
+
+        uint32_t i = c.aff_starts[zi];
+        const uint32_t end = inb ? c.aff_starts[zi + 1] : 0u;
+        bool hit = false;
+        // per-lane trip counts differ: loop until every lane is past its own end (or has hit)
+        while (wave_any(!hit && i < end))
+        {
+            if (!hit && i < end)
+            {
+                const float4 *px = reinterpret_cast<const float4 *>(c.aff_x + 8 * (size_t) i);
+                const float4 *py = reinterpret_cast<const float4 *>(c.aff_y + 8 * (size_t) i);
+                const float4 *pz = reinterpret_cast<const float4 *>(c.aff_z + 8 * (size_t) i);
+                const float4 x0 = px[0], x1 = px[1], y0 = py[0], y1 = py[1], z0 = pz[0], z1 = pz[1];
+                bool h = false;
+                h |= sql2_3(x0.x, y0.x, z0.x, x, y, z) <= rc_sq;
+                h |= sql2_3(x0.y, y0.y, z0.y, x, y, z) <= rc_sq;
+                h |= sql2_3(x0.z, y0.z, z0.z, x, y, z) <= rc_sq;
+                h |= sql2_3(x0.w, y0.w, z0.w, x, y, z) <= rc_sq;
+                h |= sql2_3(x1.x, y1.x, z1.x, x, y, z) <= rc_sq;
+                h |= sql2_3(x1.y, y1.y, z1.y, x, y, z) <= rc_sq;
+                h |= sql2_3(x1.z, y1.z, z1.z, x, y, z) <= rc_sq;
+                h |= sql2_3(x1.w, y1.w, z1.w, x, y, z) <= rc_sq;
+                hit = h;
+                ++i;
+            }
+        }
+        return hit;
+    }
+
+    // sphere_environment_in_collision (collision/validity.hh:47-158) for one robot sphere, per lane.
+    //  * returns this lane's own "hits something" flag; the caller folds it over the rake with group_any.
+    //  * the sorted early-break is rake-wide in the reference (all 8 lanes must agree).  Lists are sorted
+    //    by min_distance, so "all lanes have min_distance - max_extent >= 0" is the same predicate
+    //    evaluated on the rake's largest max_extent: ext = group_max(max_extent).
+    //  * max_extent uses the correctly rounded sqrt (the reference's v*rsqrt_ps(v) is vendor-defined).
+    //  * `active` only prunes work: lanes that cannot influence the result stop driving the loops.
+    template <int G>
+    __device__ __forceinline__ bool env_hit(const EnvView &E, float x, float y, float z, float r, bool active)
+    {
+        const EnvDev &D = *E.dev;
+        const float ext = group_max<G>(sqrtf(dot3(x, y, z, x, y, z)) + r);
+        bool hit = false;
+
+        {
+            lds_cptr rec = E.lds + D.off_sphere;
+            bool live = active;
+            for (uint32_t i = 0; i < D.n_sphere; ++i, rec += kSphereRec)
+            {
+                const v4f a = lds_load4(rec);
+                live = live && neg(rec[4] - ext) && !hit;
+                if (!wave_any(live)) break;
+                const bool h = neg(sphere_sphere_sql2(a.x, a.y, a.z, a.w, x, y, z, r));
+                hit |= (live && h);
+            }
+        }
+        {
+            lds_cptr rec = E.lds + D.off_capsule;
+            bool live = active;
+            for (uint32_t i = 0; i < D.n_capsule; ++i, rec += kCapsuleRec)
+            {
+                const v4f a = lds_load4(rec);
+                const v4f b = lds_load4(rec + 4);
+                live = live && neg(rec[8] - ext) && !hit;
+                if (!wave_any(live)) break;
+                // collision/sphere_capsule.hh:8-23 (a = x1 y1 z1 xv, b = yv zv r rdv)
+                const float dot = dot3(x - a.x, y - a.y, z - a.z, a.w, b.x, b.y);
+                const float cdf = vclamp(dot * b.w, 0.F, 1.F);
+                const float sum = sql2_3(x, y, z, a.x + a.w * cdf, a.y + b.x * cdf, a.z + b.y * cdf);
+                const float rs = r + b.z;
+                hit |= (live && neg(sum - rs * rs));
+            }
+        }
+        {
+            lds_cptr rec = E.lds + D.off_zcapsule;
+            bool live = active;
+            for (uint32_t i = 0; i < D.n_zcapsule; ++i, rec += kZCapsuleRec)
+            {
+                const v4f a = lds_load4(rec);      // x1 y1 z1 zv
+                const v4f b = lds_load4(rec + 4);  // r rdv min_d 0
+                live = live && neg(b.z - ext) && !hit;
+                if (!wave_any(live)) break;
+                // collision/sphere_capsule.hh:31-45
+                const float dot = (z - a.z) * a.w;
+                const float cdf = vclamp(dot * b.y, 0.F, 1.F);
+                const float sum = sql2_3(x, y, z, a.x, a.y, a.z + a.w * cdf);
+                const float rs = r + b.x;
+                hit |= (live && neg(sum - rs * rs));
+            }
+        }
+        const float rsq = r * r;
+        {
+            lds_cptr rec = E.lds + D.off_cuboid;
+            bool live = active;
+            for (uint32_t i = 0; i < D.n_cuboid; ++i, rec += kCuboidRec)
+            {
+                const v4f a = lds_load4(rec);       // x y z a1x
+                const v4f b = lds_load4(rec + 4);   // a1y a1z a2x a2y
+                const v4f c = lds_load4(rec + 8);   // a2z a3x a3y a3z
+                const v4f d = lds_load4(rec + 12);  // r1 r2 r3 min_d
+                live = live && neg(d.w - ext) && !hit;
+                if (!wave_any(live)) break;
+                // collision/sphere_cuboid.hh:8-27
+                const float xs = x - a.x, ys = y - a.y, zs = z - a.z;
+                const float a1 = x86_max(vabs(dot3(a.w, b.x, b.y, xs, ys, zs)) - d.x, 0.f);
+                const float a2 = x86_max(vabs(dot3(b.z, b.w, c.x, xs, ys, zs)) - d.y, 0.f);
+                const float a3 = x86_max(vabs(dot3(c.y, c.z, c.w, xs, ys, zs)) - d.z, 0.f);
+                hit |= (live && neg(dot3(a1, a2, a3, a1, a2, a3) - rsq));
+            }
+        }
+        {
+            lds_cptr rec = E.lds + D.off_zcuboid;
+            bool live = active;
+            for (uint32_t i = 0; i < D.n_zcuboid; ++i, rec += kZCuboidRec)
+            {
+                const v4f a = lds_load4(rec);      // x y z a1x
+                const v4f b = lds_load4(rec + 4);  // a1y a2x a2y r1
+                const v4f c = lds_load4(rec + 8);  // r2 r3 min_d 0
+                live = live && neg(c.z - ext) && !hit;
+                if (!wave_any(live)) break;
+                // collision/sphere_cuboid.hh:35-52
+                const float xs = x - a.x, ys = y - a.y, zs = z - a.z;
+                const float a1 = x86_max(vabs((a.w * xs) + (b.x * ys)) - b.w, 0.f);
+                const float a2 = x86_max(vabs((b.y * xs) + (b.z * ys)) - c.x, 0.f);
+                const float a3 = x86_max(vabs(zs) - c.y, 0.f);
+                hit |= (live && neg(dot3(a1, a2, a3, a1, a2, a3) - rsq));
+            }
+        }
+        for (uint32_t ci = 0; ci < D.n_capt; ++ci)
+        {
+            const bool act = active && !hit;
+            if (!wave_any(act)) break;
+            const float *tests = (ci == 0) ? E.capt0_tests : D.capt[ci].tests;
+            hit |= capt_collides(D.capt[ci], tests, x, y, z, r, act);
+        }
+        return hit;
+    }
+
+    // One link's environment group (robots/panda.hh:5629-6010): `if (hit(bounding)) { any fine sphere hits }`.
+    // Sphere centres of the link are staged in this wave's LDS slab: slab[(3*s + k) * 64 + lane], s = 0 is the
+    // bounding sphere.  Returns the rake-level "this group reports a collision".
+    // `active` (rake-uniform) only prunes work for rakes whose answer is already known.
+    // Tab::radius(i) reads the robot's __constant__ radius table (uniform index -> scalar load).
+    template <int G, typename Tab>
+    __device__ __noinline__ bool
+    env_group(const EnvView E, lds_cptr slab, const int n_fine, const int radii_offset, const bool active)
+    {
+        const bool gate =
+            group_any<G>(env_hit<G>(E, slab[0], slab[kWave], slab[2 * kWave], Tab::radius(radii_offset), active));
+        bool h = false;
+        for (int s = 1; s <= n_fine; ++s)
+        {
+            const bool act = gate && !h;
+            if (!wave_any(act)) break;
+            lds_cptr p = slab + 3 * s * kWave;
+            h |= group_any<G>(env_hit<G>(E, p[0], p[kWave], p[2 * kWave], Tab::radius(radii_offset + s), act));
+        }
+        return gate && h;
+    }
+}  // namespace vmv
