@@ -1,0 +1,145 @@
+"""HIP path vs oracle, through the C ABI, on a real MI355X.  Bit-exact on every boolean and every FK word."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from envs import make_env
+from oracle_lib import CAGE_GOAL, CAGE_START
+from test_oracle_pins import mt19937_uniform_configs
+
+pytestmark = pytest.mark.gpu
+ROBOTS = ["panda", "ur5", "fetch", "baxter"]
+KINDS = ["empty", "cage", "shell64", "mixed", "capt"]
+
+
+def uniform_configs(oracle, name, n, seed):
+    rid = oracle.robot(name)
+    lo, span = oracle.bounds(rid)
+    rng = np.random.default_rng(seed)
+    return rid, (lo + span * rng.random((n, len(lo)), dtype=np.float32)).astype(np.float32)
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _device(vamp):
+    assert vamp.device_count() >= 1, "no HIP device visible"
+    vamp.set_device(0)
+
+
+@pytest.mark.parametrize("name", ROBOTS)
+@pytest.mark.parametrize("kind", KINDS)
+def test_validate_batch_bit_exact(vamp, oracle, name, kind):
+    env, oenv = make_env(kind, oracle, name)
+    n = 20000 if kind != "capt" else 6000
+    rid, q = uniform_configs(oracle, name, n, seed=hash((name, kind)) % 1000)
+    got = getattr(vamp, name).validate_batch(q, env)
+    want = oracle.validate_batch(rid, oenv, q, threads=8)
+    assert got.dtype == bool and got.shape == (n,)
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("name", ROBOTS)
+@pytest.mark.parametrize("kind", ["empty", "shell64", "mixed", "capt"])
+def test_validate_motion_batch_bit_exact(vamp, oracle, name, kind):
+    """Edges with distinct configurations per rake lane: exercises the 8-lane "any lane" gating."""
+    env, oenv = make_env(kind, oracle, name)
+    n = 1500 if kind != "capt" else 600
+    rid, a = uniform_configs(oracle, name, n, seed=7)
+    rng = np.random.default_rng(8)
+    b = (a + rng.normal(0, 0.35, a.shape)).astype(np.float32)
+    b[::7] = a[::7]  # zero-length edges: n = 1, block = start
+    got = getattr(vamp, name).validate_motion_batch(a, b, env)
+    want = oracle.validate_motion_batch(rid, oenv, a, b)
+    assert np.array_equal(got, want)
+    assert 0 < want.sum() < n or kind == "mixed" or name == "baxter"
+
+
+@pytest.mark.parametrize("name", ROBOTS)
+def test_fk_bit_exact_vs_golden_and_oracle(vamp, oracle, golden_dir, name):
+    g = np.load(os.path.join(golden_dir, f"fk_{name}.npz"))
+    n_fine = int(g["n_fine"])
+    got = getattr(vamp, name).fk_batch(g["q"])
+    assert got.shape == (len(g["q"]), n_fine, 4)
+    assert np.array_equal(got.view(np.uint32), np.ascontiguousarray(g["spheres"][:, :n_fine]).view(np.uint32))
+    assert np.abs(got[..., :3] - g["spheres"][:, :n_fine, :3]).max() <= 1e-5  # north star tolerance (met at 0)
+    spheres = getattr(vamp, name).fk(g["q"][3])
+    assert len(spheres) == n_fine and abs(spheres[5].x - float(g["spheres"][3, 5, 0])) == 0.0
+
+
+def test_reference_known_answers_on_gpu(vamp, oracle, golden_dir):
+    """The reference's own known answers, computed by the HIP path."""
+    k = json.load(open(os.path.join(golden_dir, "known_answers.json")))
+    env, _ = make_env("cage", oracle)
+    p = vamp.panda
+    assert p.validate(CAGE_START, env) is True and p.validate(CAGE_GOAL, env) is True
+    assert p.validate_motion(CAGE_START, CAGE_GOAL, env) is False
+    h = np.load(os.path.join(golden_dir, "halton_panda.npz"))["samples"]
+    assert int(p.validate_batch(h[:20000], env).sum()) == k["cage_halton_20000_valid"]
+    assert int(p.validate_motion_batch(h[:20000], h[1:20001], env).sum()) == k["cage_halton_20000_edges_valid"]
+    q = mt19937_uniform_configs(p.lower_bounds(), p.upper_bounds() - p.lower_bounds(), 100000)
+    assert int(p.validate_batch(q, env).sum()) == k["cage_mt19937_seed0_100000_valid"]
+
+
+def test_edge_cases(vamp, oracle):
+    env, oenv = make_env("shell64", oracle)
+    p = vamp.panda
+    rid, q = uniform_configs(oracle, "panda", 1000, seed=1)
+    assert p.validate_batch(q[:0], env).shape == (0,)                      # empty batch
+    for n in (1, 7, 63, 64, 65, 127, 129, 1000):                            # ragged tails of the 64-lane waves
+        assert np.array_equal(p.validate_batch(q[:n], env), oracle.validate_batch(rid, oenv, q[:n]))
+    for n in (1, 7, 8, 9, 31, 33):                                          # ragged tails of the 8-edge waves
+        a, b = q[:n], q[n:2 * n]
+        assert np.array_equal(p.validate_motion_batch(a, b, env), oracle.validate_motion_batch(rid, oenv, a, b))
+    # check_bounds (robot_helper.hh:258-262)
+    out = q[0].copy()
+    out[3] = p.lower_bounds()[3] - np.float32(0.2)
+    assert p.validate(out, vamp.Environment(), check_bounds=True) is False
+    assert p.validate(out, vamp.Environment(), check_bounds=True) == oracle.validate(rid, oracle.env(), out, True)
+    # configurations outside the bounds are still evaluated exactly
+    wild = (q[:256] * np.float32(3.0)).astype(np.float32)
+    assert np.array_equal(p.validate_batch(wild, env), oracle.validate_batch(rid, oenv, wild))
+    # default environment argument = empty environment (self-collision only)
+    assert np.array_equal(p.validate_batch(q), oracle.validate_batch(rid, oracle.env(), q))
+    with pytest.raises(TypeError):
+        p.validate_batch(q[:, :6], env)
+
+
+def test_environment_rebuild_after_mutation(vamp, oracle):
+    env, oenv = make_env("cage", oracle)
+    rid, q = uniform_configs(oracle, "panda", 4000, seed=2)
+    first = vamp.panda.validate_batch(q, env)
+    env.add_sphere(vamp.Sphere([0.0, 0.0, 1.1], 0.25))
+    oenv.add_sphere(0.0, 0.0, 1.1, 0.25)
+    second = vamp.panda.validate_batch(q, env)
+    assert np.array_equal(second, oracle.validate_batch(rid, oenv, q)) and second.sum() < first.sum()
+
+
+def test_full_size_properties(vamp, oracle):
+    """BASELINE config 2 at full size (1,048,576 configs): size-independent properties + sampled oracle parity."""
+    torch = pytest.importorskip("torch")
+    env, oenv = make_env("shell64", oracle)
+    p = vamp.panda
+    n = 1 << 20
+    rid, q = uniform_configs(oracle, "panda", n, seed=11)
+    tq = torch.from_numpy(q).cuda()
+    v = p.validate_batch(tq, env)
+    assert v.dtype == torch.bool and v.shape == (n,)
+    v = v.cpu().numpy()
+    assert 0.55 < v.mean() < 0.70                                  # ~63 % valid
+    # permutation equivariance: the answer for a configuration does not depend on its position / wave
+    perm = np.random.default_rng(0).permutation(n)
+    assert np.array_equal(p.validate_batch(tq[torch.from_numpy(perm).cuda()].contiguous(), env).cpu().numpy(), v[perm])
+    # batch-split invariance
+    assert np.array_equal(p.validate_batch(tq[123457:654321].contiguous(), env).cpu().numpy(), v[123457:654321])
+    # a zero-length edge is the configuration check (validate_motion<.., 1>(q, q) is what validate() calls)
+    sub = tq[: 1 << 16].contiguous()
+    assert np.array_equal(p.validate_motion_batch(sub, sub, env).cpu().numpy(), v[: 1 << 16])
+    # monotonicity: removing obstacles can only make configurations valid
+    empty = p.validate_batch(tq, vamp.Environment()).cpu().numpy()
+    assert not np.any(v & ~empty)
+    # sampled oracle parity at full size
+    idx = np.random.default_rng(1).choice(n, 50000, replace=False)
+    assert np.array_equal(v[idx], oracle.validate_batch(rid, oenv, q[idx], threads=8))
+    # host-buffer path == device-buffer path
+    assert np.array_equal(p.validate_batch(q[:200000], env), v[:200000])

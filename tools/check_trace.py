@@ -91,6 +91,17 @@ def check(name, n=20000, seed=1, verbose=True):
         print("  descale differs", model["descale"], consts["d_m"])
         ok = False
     q = (rng.random((n, len(lo)), dtype=np.float32) * span + lo).astype(np.float32)
+    # special configurations: exact zeros / quarter turns, where FK terms cancel and 1e-18 constants become visible
+    special = [np.zeros(len(lo))]
+    for j in range(len(lo)):
+        for v in (np.pi / 2, -np.pi / 2, np.pi, 1e-3):
+            s_ = np.zeros(len(lo))
+            s_[j] = v
+            special.append(s_)
+    for _ in range(400):
+        special.append(rng.choice([0, np.pi / 2, -np.pi / 2, np.pi, -np.pi, np.pi / 4], len(lo)))
+    q = np.concatenate([np.array(special, np.float32), q]).astype(np.float32)
+    n = q.shape[0]
     yref = R.Evaluator(prog, rv).run(q)  # [n_y, N]
     ymod = eval_model(model, q, rv)  # [S, 4, N]
     S = ymod.shape[0]

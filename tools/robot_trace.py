@@ -490,9 +490,11 @@ def trace(urdf, srdf, joint_names, end_effector=None, bounding=None, resolution=
             r32 = np.float32(r)
         # the bounding centre is kept as fp32 in the frame of the link's movable joint
         p_joint = fr.act(c).astype(np.float32).astype(np.float64)
+        p_joint[np.abs(p_joint) < 1e-12] = 0.0  # round-off of this solver / of the fixed-frame product is not geometry
         for axis, val in (bounding_residue or {}).get(ln, {}).items():
             p_joint[int(axis)] = val
-        spheres.append(dict(link=ln, r=float(r32), expr=world(jid, p_joint), local=c, bounding=True))
+        spheres.append(dict(link=ln, r=float(r32), expr=world(jid, p_joint), local=c, bounding=True,
+                            joint_frame=[float(v) for v in p_joint], static=(oM[jid] is None)))
         bound_index[ln] = len(spheres) - 1
 
     # groups
@@ -660,6 +662,8 @@ def to_json(tr: Traced):
         outputs=[[list(c) for c in o] for o in outputs],
         env_groups=tr.env_groups,
         self_groups=tr.self_groups,
+        bounding_joint_frame={sp["link"]: sp["joint_frame"] for sp in tr.spheres if sp.get("bounding")},
+        bounding_static={sp["link"]: sp["static"] for sp in tr.spheres if sp.get("bounding")},
     )
     return model
 
@@ -667,6 +671,10 @@ def to_json(tr: Traced):
 ROBOTS = {
     "panda": dict(urdf="panda/panda_spherized.urdf", srdf="panda/panda.srdf", resolution=32,
                   end_effector="panda_grasptarget",
+                  # ~1e-18 of solver round-off the reference's generated code carries in the hand's bounding centre
+                  # (robots/panda.hh fkcc, y[268..270]); recorded as model data so special configurations
+                  # (e.g. q = 0, where everything else cancels) stay bit-exact.
+                  bounding_residue={"panda_hand": {0: -5.20417042793042e-18, 1: -2.16840434497101e-18}},
                   joints=["panda_joint1", "panda_joint2", "panda_joint3", "panda_joint4", "panda_joint5",
                           "panda_joint6", "panda_joint7"]),
     "ur5": dict(urdf="ur5/ur5_spherized.urdf", srdf="ur5/ur5.srdf", resolution=32,
@@ -682,7 +690,12 @@ ROBOTS = {
                   # the reference used left ~1e-17 of solver round-off there (robots/fetch.hh fkcc, bounding
                   # spheres of the three static links).  Recorded as model data so the boolean stays bit-exact.
                   bounding_residue={"base_link": {1: -1.875 * 2.0 ** -55}, "torso_fixed_link": {1: 2.0 ** -55},
-                                    "head_pan_link": {1: -1.75 * 2.0 ** -56}},
+                                    "head_pan_link": {1: -1.75 * 2.0 ** -56},
+                                    "shoulder_lift_link": {2: 1.73472347597681e-18},
+                                    "upperarm_roll_link": {2: -1.73472347597681e-18},
+                                    "elbow_flex_link": {2: 1.73472347597681e-18},
+                                    "forearm_roll_link": {2: -1.73472347597681e-18},
+                                    "wrist_flex_link": {2: 4.33680868994202e-18}},
                   joints=["torso_lift_joint", "shoulder_pan_joint", "shoulder_lift_joint", "upperarm_roll_joint",
                           "elbow_flex_joint", "forearm_roll_joint", "wrist_flex_joint", "wrist_roll_joint"]),
     "baxter": dict(urdf="baxter/baxter_spherized.urdf", srdf="baxter/baxter.srdf", resolution=64,
