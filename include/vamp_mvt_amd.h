@@ -47,6 +47,7 @@ const char *vmv_last_error(void);
 /* ---- devices ----------------------------------------------------------------------------------------- */
 int vmv_device_count(int *count);
 int vmv_set_device(int device);
+int vmv_get_device(int *device);
 
 /* ---- robots (replaces the per-robot submodule constants, bindings/robot_helper.hh:326-360) ------------ */
 int vmv_num_robots(void);

@@ -234,9 +234,14 @@ class Environment:
         return h
 
     def handle(self):
-        """Finalized C-ABI handle (sorted + uploaded to the current device)."""
+        """Finalized C-ABI handle (sorted + uploaded to the current device; rebuilt if the device changed)."""
+        dev = ctypes.c_int(-1)
+        lib.vmv_get_device(ctypes.byref(dev))
+        if self._handle is not None and self._device != dev.value:
+            self._dirty()
         if self._handle is None:
             self._handle = self._build()
+            self._device = dev.value
         return self._handle
 
     # -- inspection (host tables; no GPU needed) ----------------------------------------------------------------
@@ -347,7 +352,11 @@ class _Robot(types.ModuleType):
 
     # batched calls --------------------------------------------------------------------------------------------
     def _env(self, environment):
-        return (environment if environment is not None else Environment()).handle()
+        # the default argument of the reference (`env = Environment()`): one cached empty environment, kept alive
+        # here because the C handle must outlive the call
+        if environment is None:
+            environment = _EMPTY_ENVIRONMENT
+        return environment.handle()
 
     def validate_batch(self, configurations, environment: Environment | None = None):
         """bool[n] (numpy in -> numpy out; torch CUDA tensor in -> torch.bool CUDA tensor out)."""
@@ -414,6 +423,8 @@ class _Robot(types.ModuleType):
             shifts = torch.arange(64, device=a.device, dtype=torch.int64)
             return (((bits[:, None] >> shifts[None, :]) & 1) != 0).reshape(-1)[:n]
 
+
+_EMPTY_ENVIRONMENT = Environment()
 
 for _name in robots():
     _mod = _Robot(_name)

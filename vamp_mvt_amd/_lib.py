@@ -52,6 +52,7 @@ def _load():
         "vmv_last_error": (ctypes.c_char_p, []),
         "vmv_device_count": (I, [ctypes.POINTER(I)]),
         "vmv_set_device": (I, [I]),
+        "vmv_get_device": (I, [ctypes.POINTER(I)]),
         "vmv_num_robots": (I, []),
         "vmv_robot_name": (ctypes.c_char_p, [I]),
         "vmv_robot_id": (I, [ctypes.c_char_p]),

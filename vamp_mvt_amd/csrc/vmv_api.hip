@@ -210,6 +210,12 @@ extern "C"
         VMV_HIP(hipSetDevice(device));
         return VMV_OK;
     }
+    int vmv_get_device(int *device)
+    {
+        if (!device) return VMV_ERR_INVALID_ARGUMENT;
+        VMV_HIP(hipGetDevice(device));
+        return VMV_OK;
+    }
 
     // ---- robots ----
     int vmv_num_robots(void) { return kNumRobots; }
