@@ -148,6 +148,8 @@ def emit_robot(m):
     L.append("    fkcc(const vmv::EnvView &E, const float (&q)[kDim], vmv::lds_ptr slab, const bool skip)")
     L.append("    {")
     L.append("        bool bad = skip;")
+    L.append("        // per-wave scratch words live right behind the sphere slab")
+    L.append("        const vmv::lds_ptr scratch = slab - __lane_id() + kSlabSpheres * 3 * vmv::kWave;")
     em = Emitter(m)
     for ln in links:
         g = env_by_link[ln]
@@ -157,7 +159,7 @@ def emit_robot(m):
         for si, s in enumerate(group_spheres):
             for k in range(3):
                 em.lines.append(f"        slab[{(3 * si + k)} * vmv::kWave] = {em.coord(s, k)};")
-        em.lines.append(f"        bad |= vmv::env_group<G, Tab>(E, slab, {len(g['fine'])}, {radii_off[ln]}, !bad);")
+        em.lines.append(f"        bad |= vmv::env_group<G, Tab>(E, slab, scratch, {len(g['fine'])}, {radii_off[ln]}, !bad);")
         for sg in self_by_b.get(ln, []):
             gi = m["self_groups"].index(sg)
             a_sph = sorted({p[0] for p in sg["pairs"]})

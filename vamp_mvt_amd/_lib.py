@@ -37,6 +37,13 @@ def declared_symbols(header_path: str = HEADER_PATH):
 
 
 def _load():
+    # PyTorch-ROCm bundles its own HIP runtime.  Two HIP runtimes in one process fight over the device
+    # ("No HIP GPUs are available" in whichever initialises second), so when torch is installed its runtime is
+    # loaded first and this library binds to the same libamdhip64 (torch stays plumbing: memory, streams, RCCL).
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} not found: build it with `python __graft_entry__.py` (hipcc --offload-arch=gfx950). "

@@ -354,6 +354,18 @@ extern "C"
         for (const auto &c : env->z_cuboids)
             block.insert(block.end(), {c.p[0], c.p[1], c.p[2], c.p[3], c.p[4], c.p[6], c.p[7], c.p[12], c.p[13],
                                        c.p[14], c.min_d, 0.f});
+        // compact min_distance arrays (one per list) for the wave-wide live-prefix count
+        auto md_array = [&](auto &list, uint32_t &off)
+        {
+            while (block.size() % 4) block.push_back(0.f);
+            off = (uint32_t) block.size();
+            for (const auto &s : list) block.push_back(s.min_d);
+        };
+        md_array(env->spheres, D.off_md_sphere);
+        md_array(env->capsules, D.off_md_capsule);
+        md_array(env->z_capsules, D.off_md_zcapsule);
+        md_array(env->cuboids, D.off_md_cuboid);
+        md_array(env->z_cuboids, D.off_md_zcuboid);
         while (block.size() % 4) block.push_back(0.f);
         if (block.size() > kMaxPrimFloats)
         {

@@ -158,6 +158,7 @@ namespace vmv
         uint32_t n_floats;   // size of that block
         uint32_t n_sphere, n_capsule, n_zcapsule, n_cuboid, n_zcuboid;
         uint32_t off_sphere, off_capsule, off_zcapsule, off_cuboid, off_zcuboid;  // float offsets in the block
+        uint32_t off_md_sphere, off_md_capsule, off_md_zcapsule, off_md_cuboid, off_md_zcuboid;  // min_distance arrays
         uint32_t n_capt;
         uint32_t capt0_n_tests;  // size of capt[0].tests (candidate for LDS staging behind the primitive block)
         CaptDev capt[kMaxCapt];
@@ -247,41 +248,82 @@ namespace vmv
         return hit;
     }
 
+    // ------------------------------------------------------------------------
+    // wave-level helpers for the counted primitive loops
+    // ------------------------------------------------------------------------
+    // max over the wavefront of a NON-NEGATIVE float (compared through its bit pattern), result wave-uniform.
+    // 4 DPP steps (quad xor 1, quad xor 2, half-row mirror, row mirror) leave each 16-lane row holding its
+    // maximum; 4 v_readlane + scalar max finish.  No LDS traffic.
+    __device__ __forceinline__ float wave_max_nonneg(float v)
+    {
+        uint32_t u = f2u(v);
+        u = max(u, (uint32_t) __builtin_amdgcn_update_dpp(0, (int) u, 0xB1, 0xF, 0xF, false));   // quad_perm [1,0,3,2]
+        u = max(u, (uint32_t) __builtin_amdgcn_update_dpp(0, (int) u, 0x4E, 0xF, 0xF, false));   // quad_perm [2,3,0,1]
+        u = max(u, (uint32_t) __builtin_amdgcn_update_dpp(0, (int) u, 0x141, 0xF, 0xF, false));  // row_half_mirror
+        u = max(u, (uint32_t) __builtin_amdgcn_update_dpp(0, (int) u, 0x140, 0xF, 0xF, false));  // row_mirror
+        const uint32_t a = (uint32_t) __builtin_amdgcn_readlane((int) u, 0);
+        const uint32_t b = (uint32_t) __builtin_amdgcn_readlane((int) u, 16);
+        const uint32_t c = (uint32_t) __builtin_amdgcn_readlane((int) u, 32);
+        const uint32_t d = (uint32_t) __builtin_amdgcn_readlane((int) u, 48);
+        return u2f(max(max(a, b), max(c, d)));
+    }
+
+    // How many leading entries of a min_distance-sorted list can matter to any lane of the wave:
+    // #{ p : neg(md[p] - ext_wave) }  (the predicate is monotone along the sorted list).
+    __device__ __forceinline__ uint32_t live_prefix(lds_cptr md, const uint32_t n, const float ext_wave)
+    {
+        const uint32_t lane = __lane_id();
+        uint32_t count = 0;
+        for (uint32_t base = 0; base < n; base += kWave)
+        {
+            const uint32_t i = base + lane;
+            const bool p = (i < n) && neg(md[i < n ? i : 0] - ext_wave);
+            const uint32_t c = (uint32_t) __popcll(__ballot(p));
+            count += c;
+            if (c < (uint32_t) kWave) break;
+        }
+        return count;
+    }
+
     // sphere_environment_in_collision (collision/validity.hh:47-158) for one robot sphere, per lane.
     //  * returns this lane's own "hits something" flag; the caller folds it over the rake with group_any.
     //  * the sorted early-break is rake-wide in the reference (all 8 lanes must agree).  Lists are sorted
     //    by min_distance, so "all lanes have min_distance - max_extent >= 0" is the same predicate
     //    evaluated on the rake's largest max_extent: ext = group_max(max_extent).
     //  * max_extent uses the correctly rounded sqrt (the reference's v*rsqrt_ps(v) is vendor-defined).
-    //  * `active` only prunes work: lanes that cannot influence the result stop driving the loops.
+    //  * loops are counted: the trip count is the live prefix for the largest max_extent in the wave; each
+    //    lane still applies its own break predicate, so the per-lane answer is the reference's.
+    //  * `active` only prunes work: inactive lanes do not extend the trip counts and report no hit.
     template <int G>
     __device__ __forceinline__ bool env_hit(const EnvView &E, float x, float y, float z, float r, bool active)
     {
         const EnvDev &D = *E.dev;
         const float ext = group_max<G>(sqrtf(dot3(x, y, z, x, y, z)) + r);
+        const float ext_wave = wave_max_nonneg(active ? ext : 0.0f);
         bool hit = false;
 
+        if (D.n_sphere)
         {
             lds_cptr rec = E.lds + D.off_sphere;
-            bool live = active;
-            for (uint32_t i = 0; i < D.n_sphere; ++i, rec += kSphereRec)
+            const uint32_t n = live_prefix(E.lds + D.off_md_sphere, D.n_sphere, ext_wave);
+#pragma unroll 2
+            for (uint32_t i = 0; i < n; ++i, rec += kSphereRec)
             {
                 const v4f a = lds_load4(rec);
-                live = live && neg(rec[4] - ext) && !hit;
-                if (!wave_any(live)) break;
+                const bool live = neg(rec[4] - ext);
                 const bool h = neg(sphere_sphere_sql2(a.x, a.y, a.z, a.w, x, y, z, r));
                 hit |= (live && h);
             }
         }
+        if (D.n_capsule)
         {
             lds_cptr rec = E.lds + D.off_capsule;
-            bool live = active;
-            for (uint32_t i = 0; i < D.n_capsule; ++i, rec += kCapsuleRec)
+            const uint32_t n = live_prefix(E.lds + D.off_md_capsule, D.n_capsule, ext_wave);
+            for (uint32_t i = 0; i < n; ++i, rec += kCapsuleRec)
             {
                 const v4f a = lds_load4(rec);
                 const v4f b = lds_load4(rec + 4);
-                live = live && neg(rec[8] - ext) && !hit;
-                if (!wave_any(live)) break;
+                const bool live = neg(rec[8] - ext);
                 // collision/sphere_capsule.hh:8-23 (a = x1 y1 z1 xv, b = yv zv r rdv)
                 const float dot = dot3(x - a.x, y - a.y, z - a.z, a.w, b.x, b.y);
                 const float cdf = vclamp(dot * b.w, 0.F, 1.F);
@@ -290,15 +332,15 @@ namespace vmv
                 hit |= (live && neg(sum - rs * rs));
             }
         }
+        if (D.n_zcapsule)
         {
             lds_cptr rec = E.lds + D.off_zcapsule;
-            bool live = active;
-            for (uint32_t i = 0; i < D.n_zcapsule; ++i, rec += kZCapsuleRec)
+            const uint32_t n = live_prefix(E.lds + D.off_md_zcapsule, D.n_zcapsule, ext_wave);
+            for (uint32_t i = 0; i < n; ++i, rec += kZCapsuleRec)
             {
                 const v4f a = lds_load4(rec);      // x1 y1 z1 zv
                 const v4f b = lds_load4(rec + 4);  // r rdv min_d 0
-                live = live && neg(b.z - ext) && !hit;
-                if (!wave_any(live)) break;
+                const bool live = neg(b.z - ext);
                 // collision/sphere_capsule.hh:31-45
                 const float dot = (z - a.z) * a.w;
                 const float cdf = vclamp(dot * b.y, 0.F, 1.F);
@@ -308,17 +350,17 @@ namespace vmv
             }
         }
         const float rsq = r * r;
+        if (D.n_cuboid)
         {
             lds_cptr rec = E.lds + D.off_cuboid;
-            bool live = active;
-            for (uint32_t i = 0; i < D.n_cuboid; ++i, rec += kCuboidRec)
+            const uint32_t n = live_prefix(E.lds + D.off_md_cuboid, D.n_cuboid, ext_wave);
+            for (uint32_t i = 0; i < n; ++i, rec += kCuboidRec)
             {
                 const v4f a = lds_load4(rec);       // x y z a1x
                 const v4f b = lds_load4(rec + 4);   // a1y a1z a2x a2y
                 const v4f c = lds_load4(rec + 8);   // a2z a3x a3y a3z
                 const v4f d = lds_load4(rec + 12);  // r1 r2 r3 min_d
-                live = live && neg(d.w - ext) && !hit;
-                if (!wave_any(live)) break;
+                const bool live = neg(d.w - ext);
                 // collision/sphere_cuboid.hh:8-27
                 const float xs = x - a.x, ys = y - a.y, zs = z - a.z;
                 const float a1 = x86_max(vabs(dot3(a.w, b.x, b.y, xs, ys, zs)) - d.x, 0.f);
@@ -327,16 +369,17 @@ namespace vmv
                 hit |= (live && neg(dot3(a1, a2, a3, a1, a2, a3) - rsq));
             }
         }
+        if (D.n_zcuboid)
         {
             lds_cptr rec = E.lds + D.off_zcuboid;
-            bool live = active;
-            for (uint32_t i = 0; i < D.n_zcuboid; ++i, rec += kZCuboidRec)
+            const uint32_t n = live_prefix(E.lds + D.off_md_zcuboid, D.n_zcuboid, ext_wave);
+#pragma unroll 2
+            for (uint32_t i = 0; i < n; ++i, rec += kZCuboidRec)
             {
                 const v4f a = lds_load4(rec);      // x y z a1x
                 const v4f b = lds_load4(rec + 4);  // a1y a2x a2y r1
                 const v4f c = lds_load4(rec + 8);  // r2 r3 min_d 0
-                live = live && neg(c.z - ext) && !hit;
-                if (!wave_any(live)) break;
+                const bool live = neg(c.z - ext);
                 // collision/sphere_cuboid.hh:35-52
                 const float xs = x - a.x, ys = y - a.y, zs = z - a.z;
                 const float a1 = x86_max(vabs((a.w * xs) + (b.x * ys)) - b.w, 0.f);
@@ -345,6 +388,7 @@ namespace vmv
                 hit |= (live && neg(dot3(a1, a2, a3, a1, a2, a3) - rsq));
             }
         }
+        hit = hit && active;
         for (uint32_t ci = 0; ci < D.n_capt; ++ci)
         {
             const bool act = active && !hit;
@@ -355,25 +399,65 @@ namespace vmv
         return hit;
     }
 
-    // One link's environment group (robots/panda.hh:5629-6010): `if (hit(bounding)) { any fine sphere hits }`.
-    // Sphere centres of the link are staged in this wave's LDS slab: slab[(3*s + k) * 64 + lane], s = 0 is the
-    // bounding sphere.  Returns the rake-level "this group reports a collision".
-    // `active` (rake-uniform) only prunes work for rakes whose answer is already known.
-    // Tab::radius(i) reads the robot's __constant__ radius table (uniform index -> scalar load).
-    template <int G, typename Tab>
-    __device__ __noinline__ bool
-    env_group(const EnvView E, lds_cptr slab, const int n_fine, const int radii_offset, const bool active)
+    __device__ __forceinline__ void wave_lds_sync()
     {
+        // same-wave LDS hand-off (DS ops of one wave retire in order; this pins the compiler's order too)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+
+    constexpr int kScratchWords = 2 * kWave;  // per-wave LDS scratch behind the slab: lane list + hit flags
+
+    // One link's environment group (robots/panda.hh:5629-6010): `if (hit(bounding)) { any fine sphere hits }`.
+    //
+    // The link's sphere centres are staged in this wave's LDS slab, slab[(3*s + k) * 64 + lane] (s = 0 is the
+    // bounding sphere; `slab` already points at this lane's column).
+    //   1. gate: every lane tests its own bounding sphere (lane = configuration).
+    //   2. fine spheres: only rakes whose gate fired matter, typically a few of the 64 lanes.  Instead of
+    //      running n_fine rounds with most lanes idle, the (passing lane, fine sphere) pairs are re-dealt
+    //      over the 64 lanes, sphere-major (item = s * k + j), each lane fetching "its" sphere from the
+    //      slab column of the configuration it now works for.  k is a multiple of G and passing lanes come
+    //      in whole rakes, so the 8 lanes of a rake stay adjacent and aligned for the rake-wide max_extent.
+    //      Hits are OR-ed back per configuration through LDS flags.
+    // Returns the rake-level "this group reports a collision".  `active` (rake-uniform) only prunes work.
+    // Tab::radius(i) reads the robot's __constant__ radius table.
+    template <int G, typename Tab>
+    __device__ __noinline__ bool env_group(const EnvView E, lds_cptr slab, lds_ptr scratch, const int n_fine,
+                                           const int radii_offset, const bool active)
+    {
+        const uint32_t lane = __lane_id();
         const bool gate =
             group_any<G>(env_hit<G>(E, slab[0], slab[kWave], slab[2 * kWave], Tab::radius(radii_offset), active));
-        bool h = false;
-        for (int s = 1; s <= n_fine; ++s)
+        const uint64_t mask = __ballot(gate);
+        if (mask == 0ull) return false;
+
+        const int k = __popcll(mask);
+        typedef __attribute__((address_space(3))) uint32_t lds_u32;
+        lds_u32 *list = (lds_u32 *) scratch;
+        lds_u32 *flags = list + kWave;
+        flags[lane] = 0u;
+        if (gate) list[__popcll(mask & ((1ull << lane) - 1ull))] = lane;
+        wave_lds_sync();
+
+        lds_cptr wave_slab = slab - lane;
+        const int items = k * n_fine;
+        const float inv_k = 1.0f / (float) k;
+        for (int base = 0; base < items; base += kWave)
         {
-            const bool act = gate && !h;
-            if (!wave_any(act)) break;
-            lds_cptr p = slab + 3 * s * kWave;
-            h |= group_any<G>(env_hit<G>(E, p[0], p[kWave], p[2 * kWave], Tab::radius(radii_offset + s), act));
+            const int i = base + (int) lane;
+            const bool act = i < items;
+            // s = i / k (exact: (i + 0.5) / k is at least 0.5 / 64 away from an integer, far above fp32 error)
+            int s = (int) (((float) i + 0.5f) * inv_k);
+            s = act ? s : 0;
+            const int j = act ? (i - s * k) : 0;
+            const uint32_t src = list[j];
+            lds_cptr p = wave_slab + 3 * (s + 1) * kWave + src;
+            const bool hit = env_hit<G>(E, p[0], p[kWave], p[2 * kWave], Tab::radius(radii_offset + 1 + s), act);
+            if (hit) flags[src] = 1u;
         }
-        return gate && h;
+        wave_lds_sync();
+        const bool h = flags[lane] != 0u;
+        return gate && group_any<G>(h);
     }
 }  // namespace vmv
