@@ -71,6 +71,8 @@ def main():
     ap.add_argument("--configs", type=int, default=CONFIGS_PER_GPU, help="configurations per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=1 << 21)
+    ap.add_argument("--env", default="shell64", choices=["shell64", "empty", "cage"],
+                    help="diagnostics only: the metric is defined on shell64 (BASELINE config 2)")
     args = ap.parse_args()
 
     import numpy as np
@@ -94,6 +96,11 @@ def main():
 
     vamp.set_device(local_rank)
     spec = shell_spec(seed=0)  # 32 spheres + 32 z-aligned cuboids (BASELINE config 2)
+    if args.env == "empty":
+        spec = []
+    elif args.env == "cage":
+        from vamp_mvt_amd.workloads import SPHERE_CAGE
+        spec = [("sphere", np.array([*c, 0.2], np.float32)) for c in SPHERE_CAGE]
     env = environment_from_spec(spec)
     panda = vamp.panda
     n = args.configs
@@ -167,7 +174,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": "Panda 7-DoF, 1,048,576 uniform random configs per GPU vs 64 primitives "
                                    "(32 spheres + 32 z-aligned cuboids on a cylindrical shell), configs[1]",
-                       "configs_per_gpu": n, "primitives": 64, "valid_fraction": valid_frac,
+                       "configs_per_gpu": n, "primitives": len(spec), "env": args.env, "valid_fraction": valid_frac,
                        "exchange": "RCCL all_gather of packed validity bitmasks" if world > 1 else "none",
                        "parallelism": f"shard{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -164,9 +164,16 @@ namespace vmv
         CaptDev capt[kMaxCapt];
     };
 
+    // explicit address spaces for everything that crosses a non-inlined call: the constant space makes the
+    // environment header scalar loads (s_load), the global space makes per-lane CAPT reads global_load (not flat)
+    using env_cptr = const __attribute__((address_space(4))) EnvDev *;
+    using gf_cptr = const __attribute__((address_space(1))) float *;
+    using gu_cptr = const __attribute__((address_space(1))) uint32_t *;
+    typedef __attribute__((address_space(1))) v4f g_v4f;
+
     struct EnvView
     {
-        const EnvDev *dev;         // device memory (uniform loads)
+        env_cptr dev;              // device memory, wave-uniform (scalar loads)
         lds_cptr lds;              // primitive block in LDS
         const float *capt0_tests;  // split planes of point cloud 0: LDS copy when staged, else dev->capt[0].tests
     };
@@ -193,26 +200,27 @@ namespace vmv
     // CAPT::collides_simd (collision/capt.hh:428-512), one lane.  The reference's `inbounds.none()` early
     // returns do not change any lane's answer, so a lane's result is independent of its rake neighbours.
     __device__ __forceinline__ bool
-    capt_collides(const CaptDev &c, const float *tests, float x, float y, float z, float r, bool active)
+    capt_collides(env_cptr D, const uint32_t ci, const float *tests, float x, float y, float z, float r, bool active)
     {
         bool inb = active;
-        inb = inb && (x + r >= c.aabb_top[0]) && (x - r <= c.aabb_top[3]);
-        inb = inb && (y + r >= c.aabb_top[1]) && (y - r <= c.aabb_top[4]);
-        inb = inb && (z + r >= c.aabb_top[2]) && (z - r <= c.aabb_top[5]);
+        inb = inb && (x + r >= D->capt[ci].aabb_top[0]) && (x - r <= D->capt[ci].aabb_top[3]);
+        inb = inb && (y + r >= D->capt[ci].aabb_top[1]) && (y - r <= D->capt[ci].aabb_top[4]);
+        inb = inb && (z + r >= D->capt[ci].aabb_top[2]) && (z - r <= D->capt[ci].aabb_top[5]);
         if (!wave_any(inb)) return false;
 
+        const uint32_t nlog2 = D->capt[ci].nlog2;
         uint32_t idx = (uint32_t) (x >= tests[0]) + 1u;
         uint32_t k = 1;
-        for (uint32_t i = 1; i < c.nlog2; ++i)
+        for (uint32_t i = 1; i < nlog2; ++i)
         {
             const float ck = (k == 0) ? x : (k == 1) ? y : z;
             idx = (idx << 1) + (uint32_t) (ck >= tests[idx]) + 1u;
             k = (k == 2) ? 0 : k + 1;
         }
-        const uint32_t zi = idx - c.n_tests;
-        const float rr = r + c.r_point;
+        const uint32_t zi = idx - D->capt[ci].n_tests;
+        const float rr = r + D->capt[ci].r_point;
         const float rc_sq = rr * rr;
-        const float *bb = c.aabbs + 6 * (size_t) zi;
+        const gf_cptr bb = (gf_cptr) D->capt[ci].aabbs + 6 * (size_t) zi;
         const float d0 = x - vclamp(x, bb[0], bb[3]);
         const float d1 = y - vclamp(y, bb[1], bb[4]);
         const float d2 = z - vclamp(z, bb[2], bb[5]);
@@ -220,18 +228,20 @@ namespace vmv
         inb = inb && (distsq <= rc_sq);
         if (!wave_any(inb)) return false;
 
-        uint32_t i = c.aff_starts[zi];
-        const uint32_t end = inb ? c.aff_starts[zi + 1] : 0u;
+        const gu_cptr starts = (gu_cptr) D->capt[ci].aff_starts;
+        uint32_t i = starts[zi];
+        const uint32_t end = inb ? starts[zi + 1] : 0u;
+        const gf_cptr ax = (gf_cptr) D->capt[ci].aff_x, ay = (gf_cptr) D->capt[ci].aff_y, az = (gf_cptr) D->capt[ci].aff_z;
         bool hit = false;
         // per-lane trip counts differ: loop until every lane is past its own end (or has hit)
         while (wave_any(!hit && i < end))
         {
             if (!hit && i < end)
             {
-                const float4 *px = reinterpret_cast<const float4 *>(c.aff_x + 8 * (size_t) i);
-                const float4 *py = reinterpret_cast<const float4 *>(c.aff_y + 8 * (size_t) i);
-                const float4 *pz = reinterpret_cast<const float4 *>(c.aff_z + 8 * (size_t) i);
-                const float4 x0 = px[0], x1 = px[1], y0 = py[0], y1 = py[1], z0 = pz[0], z1 = pz[1];
+                const g_v4f *px = (const g_v4f *) (ax + 8 * (size_t) i);
+                const g_v4f *py = (const g_v4f *) (ay + 8 * (size_t) i);
+                const g_v4f *pz = (const g_v4f *) (az + 8 * (size_t) i);
+                const v4f x0 = px[0], x1 = px[1], y0 = py[0], y1 = py[1], z0 = pz[0], z1 = pz[1];
                 bool h = false;
                 h |= sql2_3(x0.x, y0.x, z0.x, x, y, z) <= rc_sq;
                 h |= sql2_3(x0.y, y0.y, z0.y, x, y, z) <= rc_sq;
@@ -246,6 +256,24 @@ namespace vmv
             }
         }
         return hit;
+    }
+
+    // Values that are the same in every lane but reach a non-inlined function in VGPRs (the calling convention
+    // passes arguments in vector registers): re-materialise them as scalars so that loads through them are
+    // s_load and loops over them are scalar loops instead of exec-masked vector loops.
+    __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+    __device__ __forceinline__ uint32_t uniform(uint32_t v) { return (uint32_t) __builtin_amdgcn_readfirstlane((int) v); }
+    __device__ __forceinline__ uint64_t uniform(uint64_t v)
+    {
+        const uint32_t lo = uniform((uint32_t) v), hi = uniform((uint32_t) (v >> 32));
+        return ((uint64_t) hi << 32) | lo;
+    }
+    __device__ __forceinline__ const float *uniform(const float *p) { return (const float *) uniform((uint64_t) p); }
+    __device__ __forceinline__ env_cptr uniform(env_cptr p) { return (env_cptr) uniform((uint64_t) p); }
+    __device__ __forceinline__ lds_cptr uniform(lds_cptr p)
+    {
+        const uint32_t a = (uint32_t) (uintptr_t) p;  // LDS addresses are 32-bit
+        return (lds_cptr) (uintptr_t) (uint32_t) __builtin_amdgcn_readfirstlane((int) a);
     }
 
     // ------------------------------------------------------------------------
@@ -297,7 +325,8 @@ namespace vmv
     template <int G>
     __device__ __forceinline__ bool env_hit(const EnvView &E, float x, float y, float z, float r, bool active)
     {
-        const EnvDev &D = *E.dev;
+        const env_cptr Dp = E.dev;
+#define D (*Dp)
         const float ext = group_max<G>(sqrtf(dot3(x, y, z, x, y, z)) + r);
         const float ext_wave = wave_max_nonneg(active ? ext : 0.0f);
         bool hit = false;
@@ -393,10 +422,11 @@ namespace vmv
         {
             const bool act = active && !hit;
             if (!wave_any(act)) break;
-            const float *tests = (ci == 0) ? E.capt0_tests : D.capt[ci].tests;
-            hit |= capt_collides(D.capt[ci], tests, x, y, z, r, act);
+            const float *tests = (ci == 0) ? E.capt0_tests : (const float *) D.capt[ci].tests;
+            hit |= capt_collides(Dp, ci, tests, x, y, z, r, act);
         }
         return hit;
+#undef D
     }
 
     __device__ __forceinline__ void wave_lds_sync()
@@ -423,10 +453,13 @@ namespace vmv
     // Returns the rake-level "this group reports a collision".  `active` (rake-uniform) only prunes work.
     // Tab::radius(i) reads the robot's __constant__ radius table.
     template <int G, typename Tab>
-    __device__ __noinline__ bool env_group(const EnvView E, lds_cptr slab, lds_ptr scratch, const int n_fine,
-                                           const int radii_offset, const bool active)
+    __device__ __noinline__ bool env_group(const EnvView E_, lds_cptr slab, lds_ptr scratch_, const int n_fine_,
+                                           const int radii_offset_, const bool active)
     {
         const uint32_t lane = __lane_id();
+        const EnvView E{uniform(E_.dev), uniform(E_.lds), uniform(E_.capt0_tests)};
+        const lds_ptr scratch = (lds_ptr) uniform((lds_cptr) scratch_);
+        const int n_fine = uniform(n_fine_), radii_offset = uniform(radii_offset_);
         const bool gate =
             group_any<G>(env_hit<G>(E, slab[0], slab[kWave], slab[2 * kWave], Tab::radius(radii_offset), active));
         const uint64_t mask = __ballot(gate);
@@ -440,7 +473,7 @@ namespace vmv
         if (gate) list[__popcll(mask & ((1ull << lane) - 1ull))] = lane;
         wave_lds_sync();
 
-        lds_cptr wave_slab = slab - lane;
+        lds_cptr wave_slab = uniform(slab - lane);
         const int items = k * n_fine;
         const float inv_k = 1.0f / (float) k;
         for (int base = 0; base < items; base += kWave)
