@@ -186,7 +186,7 @@ def main():
             "kernel_checks_per_s": n / (kernel_ms * 1e-3),
         }
         if world == 1 and not args.no_cpu_baseline:
-            threads = min(os.cpu_count() or 1, 64)
+            threads = max(1, min(len(os.sched_getaffinity(0)), 16))  # the box's CPU share for one GPU
             out["cpu_baseline"] = cpu_baseline(spec, args.cpu_sample, threads)
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -3,15 +3,18 @@
 
 Kernel-side shape of one robot:
 
-  template <int G> bool fkcc(E, q[dim], slab)   per lane: "this rake is in collision"
+  template <int G> bool fkcc_env(E, q[dim], slab, skip)   per lane: "an environment group of this rake collides"
+  template <int G> bool fkcc_self(q[dim], skip)           per lane: "a self-collision group of this rake collides"
 
-  * the FK op tape is emitted link by link along the kinematic chain, each link's ops just before its checks,
-    so only the chain state and the spheres of links that appear on the A side of a self-collision group stay
-    live in VGPRs;
-  * the current link's spheres (bounding first) are written to the wave's LDS slab (lane-contiguous) and
-    the environment group loop / self-collision B-side loops index that slab with a wave-uniform index;
-  * self-collision groups (A, B) run when B is the current link: A's spheres are named registers, unrolled;
-    (r_a + r_b)^2 comes from a constant table computed here with the same two fp32 roundings.
+  The reference's fkcc is the OR of the two; they are separate device functions (and separate kernels) because
+  their resource profiles differ: the environment half needs an LDS slab and few registers (4+ waves per SIMD hide
+  the LDS latency of the primitive loops), the self-collision half needs no LDS and many registers.
+
+  * the FK op tape is emitted link by link along the kinematic chain, each link's ops just before its checks;
+  * fkcc_env: the current link's spheres (bounding first, then chunks of CHUNK fine spheres) are written to the
+    wave's LDS slab (lane-contiguous); vmv::env_gate / env_fine read them with wave-uniform or re-dealt indices;
+  * fkcc_self: fully unrolled on registers; (r_a + r_b)^2 are literals computed here with the same two fp32
+    roundings as the reference (`rs = ar + br; rs * rs`).
 """
 from __future__ import annotations
 
@@ -95,6 +98,9 @@ def f32(x):
     return np.float32(x)
 
 
+CHUNK = 8  # fine spheres staged in the LDS slab at a time (slab = 1 bounding + CHUNK fine spheres per wave)
+
+
 def emit_robot(m):
     n = m["name"]
     L = []
@@ -105,47 +111,37 @@ def emit_robot(m):
     self_by_b = {}
     for g in m["self_groups"]:
         self_by_b.setdefault(g["b"], []).append(g)
+    self_links = {g["a"] for g in m["self_groups"]} | {g["b"] for g in m["self_groups"]}
 
-    # constant tables
+    # constant table: radii per link group, [bounding, fine...]
     radii_tab, radii_off = [], {}
     for ln in links:
         g = env_by_link[ln]
         radii_off[ln] = len(radii_tab)
         radii_tab += [radii[g["bound"]]] + [radii[s] for s in g["fine"]]
-    rs2_tab, rs2_off = [], {}
-    for gi, g in enumerate(m["self_groups"]):
-        a_sph = sorted({p[0] for p in g["pairs"]})
-        b_sph = sorted({p[1] for p in g["pairs"]})
-        assert g["pairs"] == [[s, t] for s in a_sph for t in b_sph]
-        assert b_sph == env_by_link[g["b"]]["fine"], "B side must be the link's fine spheres in slab order"
-        rs2_off[gi] = len(rs2_tab)
-        for t in b_sph:  # [t][a]
-            for s in a_sph:
-                rs = f32(f32(radii[s]) + f32(radii[t]))
-                rs2_tab.append(float(f32(rs * rs)))
-    max_group = max(len(g["fine"]) for g in m["env_groups"]) + 1
+    max_group = max(len(g["fine"]) for g in m["env_groups"])
+    slab_spheres = 1 + min(CHUNK, max_group)
 
     L.append(f"namespace {n}")
     L.append("{")
     L.append(f"    constexpr int kDim = {dim};")
     L.append(f"    constexpr int kNSpheres = {m['n_spheres']};")
     L.append(f"    constexpr int kResolution = {m['resolution']};")
-    L.append(f"    constexpr int kSlabSpheres = {max_group};  // largest link group incl. its bounding sphere")
+    L.append(f"    constexpr int kSlabSpheres = {slab_spheres};  // bounding sphere + one chunk of fine spheres")
     L.append(f"    __constant__ float kRadii[{len(radii_tab)}] = {{" + ", ".join(flit(v) for v in radii_tab) + "};")
-    L.append(f"    __constant__ float kRs2[{max(len(rs2_tab), 1)}] = {{" +
-             (", ".join(flit(v) for v in rs2_tab) or "0.0f") + "};")
     L.append("    struct Tab")
     L.append("    {")
     L.append("        static __device__ __forceinline__ float radius(int i) { return kRadii[i]; }")
     L.append("    };")
     L.append("")
 
-    # ---- fkcc -------------------------------------------------------------------------------------------
-    L.append("    // Robot::fkcc<rake> (reference robots/%s.hh, `fkcc`): true = rake in collision." % n)
-    L.append("    template <int G>")
+    # ---- environment half of fkcc ------------------------------------------------------------------------
+    L.append("    // Environment half of Robot::fkcc<rake> (reference robots/%s.hh `fkcc`, \"environment vs. robot" % n)
+    L.append("    // collisions\"): true = some link group of this rake reports a collision.")
     L.append("    // `skip` (rake-uniform): this rake's answer is not needed; it only keeps the lanes converged.")
+    L.append("    template <int G>")
     L.append("    __device__ __forceinline__ bool")
-    L.append("    fkcc(const vmv::EnvView &E, const float (&q)[kDim], vmv::lds_ptr slab, const bool skip)")
+    L.append("    fkcc_env(const vmv::EnvView &E, const float (&q)[kDim], vmv::lds_ptr slab, const bool skip)")
     L.append("    {")
     L.append("        bool bad = skip;")
     L.append("        // per-wave scratch words live right behind the sphere slab")
@@ -153,37 +149,63 @@ def emit_robot(m):
     em = Emitter(m)
     for ln in links:
         g = env_by_link[ln]
-        group_spheres = [g["bound"]] + g["fine"]
-        em.lines.append(f"        // ---- {ln}: {len(g['fine'])} spheres")
-        em.need(group_spheres)
-        for si, s in enumerate(group_spheres):
+        fine = g["fine"]
+        chunks = [fine[i:i + CHUNK] for i in range(0, len(fine), CHUNK)]
+        em.lines.append(f"        // ---- {ln}: {len(fine)} spheres")
+        em.need([g["bound"]] + fine)
+
+        def stage(slot, s, indent):
             for k in range(3):
-                em.lines.append(f"        slab[{(3 * si + k)} * vmv::kWave] = {em.coord(s, k)};")
-        em.lines.append(f"        bad |= vmv::env_group<G, Tab>(E, slab, scratch, {len(g['fine'])}, {radii_off[ln]}, !bad);")
+                em.lines.append(f"{indent}slab[{3 * slot + k} * vmv::kWave] = {em.coord(s, k)};")
+
+        stage(0, g["bound"], "        ")
+        for si, s in enumerate(chunks[0]):
+            stage(1 + si, s, "        ")
+        em.lines.append("        {")
+        em.lines.append(f"            const bool gate = vmv::env_gate<G, Tab>(E, slab, scratch, {radii_off[ln]}, !bad);")
+        em.lines.append("            if (vmv::wave_any(gate))")
+        em.lines.append("            {")
+        done = 0
+        for ci, ch in enumerate(chunks):
+            if ci > 0:
+                for si, s in enumerate(ch):
+                    stage(1 + si, s, "                ")
+            em.lines.append(f"                vmv::env_fine<G, Tab>(E, slab, scratch, {len(ch)}, {radii_off[ln] + 1 + done});")
+            done += len(ch)
+        em.lines.append("                bad |= gate && vmv::group_any<G>(vmv::env_flag(scratch));")
+        em.lines.append("            }")
+        em.lines.append("        }")
+    L += em.lines
+    L.append("        return bad;")
+    L.append("    }")
+    L.append("")
+
+    # ---- self-collision half of fkcc -----------------------------------------------------------------------
+    L.append("    // Self-collision half of Robot::fkcc<rake> (\"robot self-collisions\"): registers only.")
+    L.append("    template <int G>")
+    L.append("    __device__ __forceinline__ bool fkcc_self(const float (&q)[kDim], const bool skip)")
+    L.append("    {")
+    L.append("        bool bad = skip;")
+    em = Emitter(m)
+    for ln in links:
         for sg in self_by_b.get(ln, []):
-            gi = m["self_groups"].index(sg)
+            ba, bb = sg["bound_a"], sg["bound_b"]
             a_sph = sorted({p[0] for p in sg["pairs"]})
-            ba = sg["bound_a"]
-            rs = f32(f32(radii[ba]) + f32(radii[sg["bound_b"]]))
-            rs2b = float(f32(rs * rs))
-            em.need(a_sph + [ba])  # already emitted (A precedes B), kept for safety
+            b_sph = sorted({p[1] for p in sg["pairs"]})
+            em.need(a_sph + b_sph + [ba, bb])
+            rs = f32(f32(radii[ba]) + f32(radii[bb]))
             em.lines.append(f"        {{  // {sg['a']} vs. {ln}")
             em.lines.append(
                 f"            const bool gate = vmv::group_any<G>(vmv::neg(vmv::sql2_3({em.coord(ba, 0)}, {em.coord(ba, 1)}, "
-                f"{em.coord(ba, 2)}, slab[0], slab[vmv::kWave], slab[2 * vmv::kWave]) - {flit(rs2b)}));")
+                f"{em.coord(ba, 2)}, {em.coord(bb, 0)}, {em.coord(bb, 1)}, {em.coord(bb, 2)}) - {flit(float(f32(rs * rs)))}));")
             em.lines.append("            if (vmv::wave_any(gate && !bad))")
             em.lines.append("            {")
             em.lines.append("                bool h = false;")
-            em.lines.append(f"                for (int s = 1; s <= {len(g['fine'])}; ++s)")
-            em.lines.append("                {")
-            em.lines.append("                    vmv::lds_cptr p = slab + 3 * s * vmv::kWave;")
-            em.lines.append("                    const float bx = p[0], by = p[vmv::kWave], bz = p[2 * vmv::kWave];")
-            em.lines.append(f"                    const float *rs2 = kRs2 + {rs2_off[gi]} + (s - 1) * {len(a_sph)};")
-            for ai, s in enumerate(a_sph):
+            for (sa, sb) in sg["pairs"]:
+                rs = f32(f32(radii[sa]) + f32(radii[sb]))
                 em.lines.append(
-                    f"                    h |= vmv::neg(vmv::sql2_3({em.coord(s, 0)}, {em.coord(s, 1)}, {em.coord(s, 2)}, "
-                    f"bx, by, bz) - rs2[{ai}]);")
-            em.lines.append("                }")
+                    f"                h |= vmv::neg(vmv::sql2_3({em.coord(sa, 0)}, {em.coord(sa, 1)}, {em.coord(sa, 2)}, "
+                    f"{em.coord(sb, 0)}, {em.coord(sb, 1)}, {em.coord(sb, 2)}) - {flit(float(f32(rs * rs)))});")
             em.lines.append("                bad |= (gate && vmv::group_any<G>(h));")
             em.lines.append("            }")
             em.lines.append("        }")
@@ -212,9 +234,14 @@ def emit_robot(m):
     L.append(f"    static constexpr int kSlabSpheres = {n}::kSlabSpheres;")
     L.append("    template <int G>")
     L.append("    static __device__ __forceinline__ bool")
-    L.append("    fkcc(const vmv::EnvView &E, const float (&q)[kDim], vmv::lds_ptr slab, const bool skip)")
+    L.append("    fkcc_env(const vmv::EnvView &E, const float (&q)[kDim], vmv::lds_ptr slab, const bool skip)")
     L.append("    {")
-    L.append(f"        return {n}::fkcc<G>(E, q, slab, skip);")
+    L.append(f"        return {n}::fkcc_env<G>(E, q, slab, skip);")
+    L.append("    }")
+    L.append("    template <int G>")
+    L.append("    static __device__ __forceinline__ bool fkcc_self(const float (&q)[kDim], const bool skip)")
+    L.append("    {")
+    L.append(f"        return {n}::fkcc_self<G>(q, skip);")
     L.append("    }")
     L.append("    static __device__ __forceinline__ void sphere_fk(const float (&q)[kDim], float4 *out)")
     L.append("    {")

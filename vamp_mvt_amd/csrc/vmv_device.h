@@ -437,42 +437,53 @@ namespace vmv
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
 
-    constexpr int kScratchWords = 2 * kWave;  // per-wave LDS scratch behind the slab: lane list + hit flags
+    constexpr int kScratchWords = 2 * kWave + 4;  // per-wave LDS scratch behind the slab: lane list, hit flags, k
 
     // One link's environment group (robots/panda.hh:5629-6010): `if (hit(bounding)) { any fine sphere hits }`.
     //
     // The link's sphere centres are staged in this wave's LDS slab, slab[(3*s + k) * 64 + lane] (s = 0 is the
-    // bounding sphere; `slab` already points at this lane's column).
-    //   1. gate: every lane tests its own bounding sphere (lane = configuration).
-    //   2. fine spheres: only rakes whose gate fired matter, typically a few of the 64 lanes.  Instead of
-    //      running n_fine rounds with most lanes idle, the (passing lane, fine sphere) pairs are re-dealt
-    //      over the 64 lanes, sphere-major (item = s * k + j), each lane fetching "its" sphere from the
-    //      slab column of the configuration it now works for.  k is a multiple of G and passing lanes come
-    //      in whole rakes, so the 8 lanes of a rake stay adjacent and aligned for the rake-wide max_extent.
-    //      Hits are OR-ed back per configuration through LDS flags.
-    // Returns the rake-level "this group reports a collision".  `active` (rake-uniform) only prunes work.
-    // Tab::radius(i) reads the robot's __constant__ radius table.
+    // bounding sphere; `slab` already points at this lane's column), in chunks of at most kChunk fine spheres
+    // so that the slab stays small enough for 4+ waves per SIMD.
+    //   env_gate   every lane tests its own bounding sphere (lane = configuration); the lanes of the rakes whose
+    //              gate fired are listed in LDS.
+    //   env_fine   for one staged chunk: only rakes whose gate fired matter, typically a few of the 64 lanes.
+    //              Instead of running n rounds with most lanes idle, the (passing lane, fine sphere) pairs are
+    //              re-dealt over the 64 lanes, sphere-major (item = s * k + j), each lane fetching "its" sphere
+    //              from the slab column of the configuration it now works for.  k is a multiple of G and passing
+    //              lanes come in whole rakes, so the 8 lanes of a rake stay adjacent and aligned for the rake-wide
+    //              max_extent.  Hits are OR-ed back per configuration through LDS flags.
+    //   env_flag   this lane's "some fine sphere of my configuration hit".
+    // `active` (rake-uniform) only prunes work.  Tab::radius(i) reads the robot's __constant__ radius table.
+    typedef __attribute__((address_space(3))) uint32_t lds_u32;
+
     template <int G, typename Tab>
-    __device__ __noinline__ bool env_group(const EnvView E_, lds_cptr slab, lds_ptr scratch_, const int n_fine_,
-                                           const int radii_offset_, const bool active)
+    __device__ __noinline__ bool
+    env_gate(const EnvView E_, lds_cptr slab, lds_ptr scratch_, const int radius_index_, const bool active)
     {
         const uint32_t lane = __lane_id();
         const EnvView E{uniform(E_.dev), uniform(E_.lds), uniform(E_.capt0_tests)};
-        const lds_ptr scratch = (lds_ptr) uniform((lds_cptr) scratch_);
-        const int n_fine = uniform(n_fine_), radii_offset = uniform(radii_offset_);
-        const bool gate =
-            group_any<G>(env_hit<G>(E, slab[0], slab[kWave], slab[2 * kWave], Tab::radius(radii_offset), active));
+        lds_u32 *list = (lds_u32 *) uniform((lds_cptr) scratch_);
+        const bool gate = group_any<G>(
+            env_hit<G>(E, slab[0], slab[kWave], slab[2 * kWave], Tab::radius(uniform(radius_index_)), active));
         const uint64_t mask = __ballot(gate);
-        if (mask == 0ull) return false;
-
-        const int k = __popcll(mask);
-        typedef __attribute__((address_space(3))) uint32_t lds_u32;
-        lds_u32 *list = (lds_u32 *) scratch;
-        lds_u32 *flags = list + kWave;
-        flags[lane] = 0u;
+        list[kWave + lane] = 0u;  // flags
         if (gate) list[__popcll(mask & ((1ull << lane) - 1ull))] = lane;
+        if (lane == 0) list[2 * kWave] = (uint32_t) __popcll(mask);
         wave_lds_sync();
+        return gate;
+    }
 
+    template <int G, typename Tab>
+    __device__ __noinline__ void
+    env_fine(const EnvView E_, lds_cptr slab, lds_ptr scratch_, const int n_fine_, const int radii_offset_)
+    {
+        const uint32_t lane = __lane_id();
+        const EnvView E{uniform(E_.dev), uniform(E_.lds), uniform(E_.capt0_tests)};
+        lds_u32 *list = (lds_u32 *) uniform((lds_cptr) scratch_);
+        lds_u32 *flags = list + kWave;
+        const int n_fine = uniform(n_fine_), radii_offset = uniform(radii_offset_);
+        const int k = (int) uniform(list[2 * kWave]);
+        if (k == 0) return;
         lds_cptr wave_slab = uniform(slab - lane);
         const int items = k * n_fine;
         const float inv_k = 1.0f / (float) k;
@@ -486,11 +497,14 @@ namespace vmv
             const int j = act ? (i - s * k) : 0;
             const uint32_t src = list[j];
             lds_cptr p = wave_slab + 3 * (s + 1) * kWave + src;
-            const bool hit = env_hit<G>(E, p[0], p[kWave], p[2 * kWave], Tab::radius(radii_offset + 1 + s), act);
+            const bool hit = env_hit<G>(E, p[0], p[kWave], p[2 * kWave], Tab::radius(radii_offset + s), act);
             if (hit) flags[src] = 1u;
         }
         wave_lds_sync();
-        const bool h = flags[lane] != 0u;
-        return gate && group_any<G>(h);
+    }
+
+    __device__ __forceinline__ bool env_flag(lds_ptr scratch)
+    {
+        return ((lds_u32 *) scratch)[kWave + __lane_id()] != 0u;
     }
 }  // namespace vmv
