@@ -98,6 +98,7 @@ def f32(x):
     return np.float32(x)
 
 
+SELF_DEAL_MAX_A = 40  # A-side spheres kept in registers for the re-dealt self-collision form
 CHUNK = 8  # fine spheres staged in the LDS slab at a time (slab = 1 bounding + CHUNK fine spheres per wave)
 
 
@@ -181,37 +182,126 @@ def emit_robot(m):
     L.append("")
 
     # ---- self-collision half of fkcc -----------------------------------------------------------------------
-    L.append("    // Self-collision half of Robot::fkcc<rake> (\"robot self-collisions\"): registers only.")
-    L.append("    template <int G>")
-    L.append("    __device__ __forceinline__ bool fkcc_self(const float (&q)[kDim], const bool skip)")
-    L.append("    {")
-    L.append("        bool bad = skip;")
-    em = Emitter(m)
-    for ln in links:
-        for sg in self_by_b.get(ln, []):
-            ba, bb = sg["bound_a"], sg["bound_b"]
-            a_sph = sorted({p[0] for p in sg["pairs"]})
-            b_sph = sorted({p[1] for p in sg["pairs"]})
-            em.need(a_sph + b_sph + [ba, bb])
-            rs = f32(f32(radii[ba]) + f32(radii[bb]))
-            em.lines.append(f"        {{  // {sg['a']} vs. {ln}")
-            em.lines.append(
-                f"            const bool gate = vmv::group_any<G>(vmv::neg(vmv::sql2_3({em.coord(ba, 0)}, {em.coord(ba, 1)}, "
-                f"{em.coord(ba, 2)}, {em.coord(bb, 0)}, {em.coord(bb, 1)}, {em.coord(bb, 2)}) - {flit(float(f32(rs * rs)))}));")
-            em.lines.append("            if (vmv::wave_any(gate && !bad))")
-            em.lines.append("            {")
-            em.lines.append("                bool h = false;")
-            for (sa, sb) in sg["pairs"]:
-                rs = f32(f32(radii[sa]) + f32(radii[sb]))
+    a_side = sorted({s for sg in m["self_groups"] for s in {p[0] for p in sg["pairs"]} | {sg["bound_a"]}})
+    dealt = len(a_side) <= SELF_DEAL_MAX_A
+    L.append("    // Self-collision half of Robot::fkcc<rake> (\"robot self-collisions\").")
+    if dealt:
+        L.append("    // Groups (A, B) run when B is the current link.  Gates (bounding pair) are per lane; the fine pairs of the")
+        L.append("    // few rakes whose gate fired are re-dealt over the 64 lanes as (passing lane, B sphere) items: B's")
+        L.append("    // sphere comes from the LDS slab column of the lane the item belongs to, A's spheres from that lane's")
+        L.append("    // registers through ds_bpermute (__shfl); hits return through LDS flags.")
+        L.append("    template <int G>")
+        L.append("    __device__ __forceinline__ bool fkcc_self(const float (&q)[kDim], vmv::lds_ptr slab, const bool skip)")
+        L.append("    {")
+        L.append("        bool bad = skip;")
+        L.append("        const unsigned lane = __lane_id();")
+        L.append("        const vmv::lds_cptr wave_slab = vmv::uniform((vmv::lds_cptr) (slab - lane));")
+        L.append("        vmv::lds_u32 *const list = (vmv::lds_u32 *) (slab - lane + kSlabSpheres * 3 * vmv::kWave);")
+        L.append("        vmv::lds_u32 *const flags = list + vmv::kWave;")
+        em = Emitter(m)
+        for ln in links:
+            groups = self_by_b.get(ln, [])
+            if not groups:
+                continue
+            g_env = env_by_link[ln]
+            fine = g_env["fine"]
+            bb = g_env["bound"]
+            chunks = [fine[i:i + CHUNK] for i in range(0, len(fine), CHUNK)]
+            em.lines.append(f"        // ---- B = {ln}: {len(fine)} spheres, {len(groups)} group(s)")
+            for sg in groups:
+                em.need(sorted({p[0] for p in sg["pairs"]}) + [sg["bound_a"]])
+            em.need([bb] + fine)
+            gate_names = []
+            for gi, sg in enumerate(groups):
+                ba = sg["bound_a"]
+                rs = f32(f32(radii[ba]) + f32(radii[bb]))
+                gn = f"gate_{links.index(ln)}_{gi}"
+                gate_names.append(gn)
                 em.lines.append(
-                    f"                h |= vmv::neg(vmv::sql2_3({em.coord(sa, 0)}, {em.coord(sa, 1)}, {em.coord(sa, 2)}, "
-                    f"{em.coord(sb, 0)}, {em.coord(sb, 1)}, {em.coord(sb, 2)}) - {flit(float(f32(rs * rs)))});")
-            em.lines.append("                bad |= (gate && vmv::group_any<G>(h));")
-            em.lines.append("            }")
+                    f"        const bool {gn} = vmv::group_any<G>(vmv::neg(vmv::sql2_3({em.coord(ba, 0)}, {em.coord(ba, 1)}, "
+                    f"{em.coord(ba, 2)}, {em.coord(bb, 0)}, {em.coord(bb, 1)}, {em.coord(bb, 2)}) - {flit(float(f32(rs * rs)))}))"
+                    f" && !bad;  // {sg['a']} vs. {ln}")
+            em.lines.append("        if (vmv::wave_any(" + " || ".join(gate_names) + "))")
+            em.lines.append("        {")
+            em.lines.append("            flags[lane] = 0u;")
+            done = 0
+            for ci, ch in enumerate(chunks):
+                for si, s in enumerate(ch):
+                    for k in range(3):
+                        em.lines.append(f"            slab[{3 * si + k} * vmv::kWave] = {em.coord(s, k)};")
+                em.lines.append("            vmv::wave_lds_sync();")
+                for gi, sg in enumerate(groups):
+                    a_sph = sorted({p[0] for p in sg["pairs"]})
+                    b_sph = sorted({p[1] for p in sg["pairs"]})
+                    assert b_sph == fine and sg["pairs"] == [[s, t] for s in a_sph for t in b_sph]
+                    em.lines.append(f"            if (vmv::wave_any({gate_names[gi]}))  // {sg['a']} vs. {ln}, chunk {ci}")
+                    em.lines.append("            {")
+                    em.lines.append(f"                const int k = vmv::deal_list(list, {gate_names[gi]});")
+                    em.lines.append(f"                const int items = k * {len(ch)};")
+                    em.lines.append("                const float inv_k = 1.0f / (float) k;")
+                    em.lines.append("                for (int base = 0; base < items; base += vmv::kWave)")
+                    em.lines.append("                {")
+                    em.lines.append("                    const int i = base + (int) lane;")
+                    em.lines.append("                    const bool act = i < items;")
+                    em.lines.append("                    const int t = act ? (int) (((float) i + 0.5f) * inv_k) : 0;")
+                    em.lines.append("                    const int j = act ? (i - t * k) : 0;")
+                    em.lines.append("                    const unsigned src = list[j];")
+                    em.lines.append("                    const vmv::lds_cptr p = wave_slab + 3 * t * vmv::kWave + src;")
+                    em.lines.append("                    const float bx = p[0], by = p[vmv::kWave], bz = p[2 * vmv::kWave];")
+                    em.lines.append(f"                    const float rb = kRadii[{radii_off[ln] + 1 + done} + t];")
+                    em.lines.append("                    bool h = false;")
+                    for s in a_sph:
+                        cs = []
+                        for k in range(3):
+                            kind, v = m["outputs"][s][k]
+                            cs.append(f"__shfl(t{v}, (int) src)" if kind == "op" else flit(v))
+                        em.lines.append("                    {")
+                        em.lines.append(f"                        const float rs = {flit(radii[s])} + rb;")
+                        em.lines.append(f"                        h |= vmv::neg(vmv::sql2_3({cs[0]}, {cs[1]}, {cs[2]}, bx, by, bz) - rs * rs);")
+                        em.lines.append("                    }")
+                    em.lines.append("                    if (h && act) flags[src] = 1u;")
+                    em.lines.append("                }")
+                    em.lines.append("                vmv::wave_lds_sync();")
+                    em.lines.append("            }")
+                done += len(ch)
+            em.lines.append("            bad |= vmv::group_any<G>(flags[lane] != 0u);")
             em.lines.append("        }")
-    L += em.lines
-    L.append("        return bad;")
-    L.append("    }")
+        L += em.lines
+        L.append("        return bad;")
+        L.append("    }")
+    else:
+        L.append("    // (A side too large for registers + shuffles: fully unrolled form on registers.)")
+        L.append("    template <int G>")
+        L.append("    __device__ __forceinline__ bool fkcc_self(const float (&q)[kDim], vmv::lds_ptr, const bool skip)")
+        L.append("    {")
+        L.append("        bool bad = skip;")
+        em = Emitter(m)
+        for ln in links:
+            for sg in self_by_b.get(ln, []):
+                ba, bb = sg["bound_a"], sg["bound_b"]
+                a_sph = sorted({p[0] for p in sg["pairs"]})
+                b_sph = sorted({p[1] for p in sg["pairs"]})
+                em.need(a_sph + b_sph + [ba, bb])
+                rs = f32(f32(radii[ba]) + f32(radii[bb]))
+                em.lines.append(f"        {{  // {sg['a']} vs. {ln}")
+                em.lines.append(
+                    f"            const bool gate = vmv::group_any<G>(vmv::neg(vmv::sql2_3({em.coord(ba, 0)}, {em.coord(ba, 1)}, "
+                    f"{em.coord(ba, 2)}, {em.coord(bb, 0)}, {em.coord(bb, 1)}, {em.coord(bb, 2)}) - {flit(float(f32(rs * rs)))}));")
+                em.lines.append("            if (vmv::wave_any(gate && !bad))")
+                em.lines.append("            {")
+                em.lines.append("                bool h = false;")
+                for (sa, sb) in sg["pairs"]:
+                    rs = f32(f32(radii[sa]) + f32(radii[sb]))
+                    em.lines.append(
+                        f"                h |= vmv::neg(vmv::sql2_3({em.coord(sa, 0)}, {em.coord(sa, 1)}, {em.coord(sa, 2)}, "
+                        f"{em.coord(sb, 0)}, {em.coord(sb, 1)}, {em.coord(sb, 2)}) - {flit(float(f32(rs * rs)))});")
+                em.lines.append("                bad |= (gate && vmv::group_any<G>(h));")
+                em.lines.append("            }")
+                em.lines.append("        }")
+        L += em.lines
+        L.append("        return bad;")
+        L.append("    }")
+    L.append(f"    constexpr bool kSelfDealt = {'true' if dealt else 'false'};")
     L.append("")
 
     # ---- sphere_fk ----------------------------------------------------------------------------------------
@@ -239,9 +329,10 @@ def emit_robot(m):
     L.append(f"        return {n}::fkcc_env<G>(E, q, slab, skip);")
     L.append("    }")
     L.append("    template <int G>")
-    L.append("    static __device__ __forceinline__ bool fkcc_self(const float (&q)[kDim], const bool skip)")
+    L.append("    static __device__ __forceinline__ bool")
+    L.append("    fkcc_self(const float (&q)[kDim], vmv::lds_ptr slab, const bool skip)")
     L.append("    {")
-    L.append(f"        return {n}::fkcc_self<G>(q, skip);")
+    L.append(f"        return {n}::fkcc_self<G>(q, slab, skip);")
     L.append("    }")
     L.append("    static __device__ __forceinline__ void sphere_fk(const float (&q)[kDim], float4 *out)")
     L.append("    {")

@@ -600,7 +600,12 @@ extern "C"
     {
         static thread_local std::string name;
         if (!robot_ok(robot) || !entry_point) return nullptr;
-        name = std::string("vmv::") + kRobots[robot].name + "::" + entry_point + "_kernel";
+        // validate_batch / validate_motion_batch run as two kernels (environment half, self-collision half);
+        // the environment kernel dominates
+        std::string ep(entry_point);
+        if (ep == "validate_batch") ep = "validate_env";
+        if (ep == "validate_motion_batch") ep = "validate_motion_env";
+        name = std::string("vmv::") + kRobots[robot].name + "::" + ep + "_kernel";
         return name.c_str();
     }
 }  // extern "C"

@@ -322,6 +322,25 @@ namespace vmv
     //  * loops are counted: the trip count is the live prefix for the largest max_extent in the wave; each
     //    lane still applies its own break predicate, so the per-lane answer is the reference's.
     //  * `active` only prunes work: inactive lanes do not extend the trip counts and report no hit.
+    // Where the wave-uniform primitive records are read from inside the counted loops.
+    //   VMV_PRIMS_SCALAR = 1: straight from the environment block through the scalar cache (s_load_dwordx4 into
+    //       SGPRs that the VALU consumes directly) - keeps the LDS pipe free for the per-lane traffic (sphere slab,
+    //       re-dealt items, min_distance prefix counts, CAPT split planes);
+    //   VMV_PRIMS_SCALAR = 0: from the LDS copy of the block (64-lane broadcast ds_read_b128).
+#ifndef VMV_PRIMS_SCALAR
+#define VMV_PRIMS_SCALAR 1
+#endif
+#if VMV_PRIMS_SCALAR
+    using rec_cptr = const __attribute__((address_space(4))) float *;
+    typedef __attribute__((address_space(4))) v4f c_v4f;
+    __device__ __forceinline__ v4f rec_load4(rec_cptr p) { return *(const c_v4f *) p; }
+#define VMV_REC_BASE(E, D) ((rec_cptr) (D).prims)
+#else
+    using rec_cptr = lds_cptr;
+    __device__ __forceinline__ v4f rec_load4(rec_cptr p) { return lds_load4(p); }
+#define VMV_REC_BASE(E, D) ((E).lds)
+#endif
+
     template <int G>
     __device__ __forceinline__ bool env_hit(const EnvView &E, float x, float y, float z, float r, bool active)
     {
@@ -333,12 +352,12 @@ namespace vmv
 
         if (D.n_sphere)
         {
-            lds_cptr rec = E.lds + D.off_sphere;
+            rec_cptr rec = VMV_REC_BASE(E, D) + D.off_sphere;
             const uint32_t n = live_prefix(E.lds + D.off_md_sphere, D.n_sphere, ext_wave);
 #pragma unroll 2
             for (uint32_t i = 0; i < n; ++i, rec += kSphereRec)
             {
-                const v4f a = lds_load4(rec);
+                const v4f a = rec_load4(rec);
                 const bool live = neg(rec[4] - ext);
                 const bool h = neg(sphere_sphere_sql2(a.x, a.y, a.z, a.w, x, y, z, r));
                 hit |= (live && h);
@@ -346,12 +365,12 @@ namespace vmv
         }
         if (D.n_capsule)
         {
-            lds_cptr rec = E.lds + D.off_capsule;
+            rec_cptr rec = VMV_REC_BASE(E, D) + D.off_capsule;
             const uint32_t n = live_prefix(E.lds + D.off_md_capsule, D.n_capsule, ext_wave);
             for (uint32_t i = 0; i < n; ++i, rec += kCapsuleRec)
             {
-                const v4f a = lds_load4(rec);
-                const v4f b = lds_load4(rec + 4);
+                const v4f a = rec_load4(rec);
+                const v4f b = rec_load4(rec + 4);
                 const bool live = neg(rec[8] - ext);
                 // collision/sphere_capsule.hh:8-23 (a = x1 y1 z1 xv, b = yv zv r rdv)
                 const float dot = dot3(x - a.x, y - a.y, z - a.z, a.w, b.x, b.y);
@@ -363,12 +382,12 @@ namespace vmv
         }
         if (D.n_zcapsule)
         {
-            lds_cptr rec = E.lds + D.off_zcapsule;
+            rec_cptr rec = VMV_REC_BASE(E, D) + D.off_zcapsule;
             const uint32_t n = live_prefix(E.lds + D.off_md_zcapsule, D.n_zcapsule, ext_wave);
             for (uint32_t i = 0; i < n; ++i, rec += kZCapsuleRec)
             {
-                const v4f a = lds_load4(rec);      // x1 y1 z1 zv
-                const v4f b = lds_load4(rec + 4);  // r rdv min_d 0
+                const v4f a = rec_load4(rec);      // x1 y1 z1 zv
+                const v4f b = rec_load4(rec + 4);  // r rdv min_d 0
                 const bool live = neg(b.z - ext);
                 // collision/sphere_capsule.hh:31-45
                 const float dot = (z - a.z) * a.w;
@@ -381,14 +400,14 @@ namespace vmv
         const float rsq = r * r;
         if (D.n_cuboid)
         {
-            lds_cptr rec = E.lds + D.off_cuboid;
+            rec_cptr rec = VMV_REC_BASE(E, D) + D.off_cuboid;
             const uint32_t n = live_prefix(E.lds + D.off_md_cuboid, D.n_cuboid, ext_wave);
             for (uint32_t i = 0; i < n; ++i, rec += kCuboidRec)
             {
-                const v4f a = lds_load4(rec);       // x y z a1x
-                const v4f b = lds_load4(rec + 4);   // a1y a1z a2x a2y
-                const v4f c = lds_load4(rec + 8);   // a2z a3x a3y a3z
-                const v4f d = lds_load4(rec + 12);  // r1 r2 r3 min_d
+                const v4f a = rec_load4(rec);       // x y z a1x
+                const v4f b = rec_load4(rec + 4);   // a1y a1z a2x a2y
+                const v4f c = rec_load4(rec + 8);   // a2z a3x a3y a3z
+                const v4f d = rec_load4(rec + 12);  // r1 r2 r3 min_d
                 const bool live = neg(d.w - ext);
                 // collision/sphere_cuboid.hh:8-27
                 const float xs = x - a.x, ys = y - a.y, zs = z - a.z;
@@ -400,14 +419,14 @@ namespace vmv
         }
         if (D.n_zcuboid)
         {
-            lds_cptr rec = E.lds + D.off_zcuboid;
+            rec_cptr rec = VMV_REC_BASE(E, D) + D.off_zcuboid;
             const uint32_t n = live_prefix(E.lds + D.off_md_zcuboid, D.n_zcuboid, ext_wave);
 #pragma unroll 2
             for (uint32_t i = 0; i < n; ++i, rec += kZCuboidRec)
             {
-                const v4f a = lds_load4(rec);      // x y z a1x
-                const v4f b = lds_load4(rec + 4);  // a1y a2x a2y r1
-                const v4f c = lds_load4(rec + 8);  // r2 r3 min_d 0
+                const v4f a = rec_load4(rec);      // x y z a1x
+                const v4f b = rec_load4(rec + 4);  // a1y a2x a2y r1
+                const v4f c = rec_load4(rec + 8);  // r2 r3 min_d 0
                 const bool live = neg(c.z - ext);
                 // collision/sphere_cuboid.hh:35-52
                 const float xs = x - a.x, ys = y - a.y, zs = z - a.z;
@@ -501,6 +520,16 @@ namespace vmv
             if (hit) flags[src] = 1u;
         }
         wave_lds_sync();
+    }
+
+    // Re-dealing support for the self-collision groups: list the lanes whose predicate holds; returns how many.
+    __device__ __forceinline__ int deal_list(lds_u32 *list, const bool pred)
+    {
+        const uint32_t lane = __lane_id();
+        const uint64_t mask = __ballot(pred);
+        if (pred) list[__popcll(mask & ((1ull << lane) - 1ull))] = lane;
+        wave_lds_sync();
+        return __popcll(mask);
     }
 
     __device__ __forceinline__ bool env_flag(lds_ptr scratch)
