@@ -100,6 +100,11 @@ int vmv_fk_batch(int robot, const float *d_q, size_t n, float *d_out, void *stre
 /* <robot>.validate(q, env) — robot_helper.hh:255-267 -> validate_motion<Robot, 8, 1>(q, q, env)
  * (planning/validate.hh:70-77) -> Robot::fkcc (robots/panda.hh:5226-10262).  One bit per configuration. */
 int vmv_validate_batch(int robot, const vmv_env *env, const float *d_q, size_t n, uint64_t *d_bits, void *stream);
+/* The two halves vmv_validate_batch launches back to back, exposed for per-kernel measurement and for callers that
+ * pipeline them: `_env` WRITES the validity words (environment half of fkcc), `_self` ANDs the self-collision half
+ * into words already written.  vmv_validate_batch == _env then _self on the same stream. */
+int vmv_validate_batch_env(int robot, const vmv_env *env, const float *d_q, size_t n, uint64_t *d_bits, void *stream);
+int vmv_validate_batch_self(int robot, const float *d_q, size_t n, uint64_t *d_bits, void *stream);
 /* validate_motion<Robot, 8, Robot::resolution>(start, goal, env) — planning/validate.hh:24-77, the call every
  * planner makes per edge (rrtc.hh:136-140, prm.hh:59, fcit.hh:238 ...).  One bit per edge. */
 int vmv_validate_motion_batch(int robot, const vmv_env *env, const float *d_start, const float *d_goal, size_t n,

@@ -1,0 +1,55 @@
+"""Planner harness: Halton restatement on CPU; RRT-Connect / batched PRM on the GPU path."""
+import os
+
+import numpy as np
+import pytest
+
+from envs import make_env
+from oracle_lib import CAGE_GOAL, CAGE_START
+
+
+def test_halton_bit_exact_vs_reference(vamp, golden_dir):
+    from vamp_mvt_amd.planning import Halton
+
+    want = np.load(os.path.join(golden_dir, "halton_panda.npz"))["samples"]
+    h = Halton(vamp.panda)
+    got = h.batch(4096)
+    assert np.array_equal(got.view(np.uint32), want[:4096].view(np.uint32))
+    h.reset()
+    h.skip(20000)
+    assert np.array_equal(h.next().view(np.uint32), want[20000].view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_rrtc_solves_the_sphere_cage(vamp, oracle):
+    """BASELINE config 1 plumbing: sphere_cage_example start -> goal (straight edge is invalid, so it must plan)."""
+    from vamp_mvt_amd.planning import Halton, RRTCSettings, rrtc, validate_path
+
+    vamp.set_device(0)
+    env, oenv = make_env("cage", oracle)
+    res = rrtc(vamp.panda, CAGE_START, CAGE_GOAL, env, RRTCSettings(range=1.0), Halton(vamp.panda))
+    assert res.solved and res.iterations > 0
+    assert np.allclose(res.path[0], CAGE_START) and np.allclose(res.path[-1], CAGE_GOAL)
+    assert validate_path(vamp.panda, res.path, env)
+    rid = oracle.robot("panda")
+    for a, b in zip(res.path[:-1], res.path[1:]):  # every segment is valid for the oracle too
+        assert oracle.validate_motion(rid, oenv, a, b)
+
+
+@pytest.mark.gpu
+def test_batched_roadmap_edges_match_oracle(vamp, oracle):
+    from vamp_mvt_amd.planning import Halton, build_roadmap
+
+    vamp.set_device(0)
+    env, oenv = make_env("cage", oracle)
+    rm = build_roadmap(vamp.panda, env, n_samples=1500, k=6, sampler=Halton(vamp.panda),
+                       extra_vertices=[CAGE_START, CAGE_GOAL])
+    rid = oracle.robot("panda")
+    assert len(rm.vertices) > 100 and rm.candidate_edges > len(rm.edges) > 0
+    assert oracle.validate_batch(rid, oenv, rm.vertices).all()
+    sel = rm.edges[:: max(1, len(rm.edges) // 300)]
+    assert oracle.validate_motion_batch(rid, oenv, rm.vertices[sel[:, 0]], rm.vertices[sel[:, 1]]).all()
+    path = rm.shortest_path(0, 1)
+    if path is not None:
+        for a, b in zip(path[:-1], path[1:]):
+            assert oracle.validate_motion(rid, oenv, rm.vertices[a], rm.vertices[b])

@@ -85,6 +85,8 @@ def _load():
         "vmv_env_capt_arrays": (I, [V, S, c_float_p, c_u32_p, c_float_p, c_float_p, c_float_p, c_float_p, c_float_p]),
         "vmv_fk_batch": (I, [I, V, S, V, V]),
         "vmv_validate_batch": (I, [I, V, V, S, V, V]),
+        "vmv_validate_batch_env": (I, [I, V, V, S, V, V]),
+        "vmv_validate_batch_self": (I, [I, V, S, V, V]),
         "vmv_validate_motion_batch": (I, [I, V, V, V, S, V, V]),
         "vmv_fk_batch_host": (I, [I, c_float_p, S, c_float_p]),
         "vmv_validate_batch_host": (I, [I, V, c_float_p, S, c_u64_p]),

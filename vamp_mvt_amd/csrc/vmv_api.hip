@@ -473,7 +473,24 @@ extern "C"
         if (!env || !d_q || !d_bits) return VMV_ERR_INVALID_ARGUMENT;
         if (!env->finalized) return VMV_ERR_NOT_FINALIZED;
         if (n == 0) return VMV_OK;
-        return kLaunchers[robot]->validate(env->launch, d_q, n, d_bits, static_cast<hipStream_t>(stream));
+        return kLaunchers[robot]->validate(env->launch, d_q, n, d_bits, static_cast<hipStream_t>(stream), 3);
+    }
+
+    int vmv_validate_batch_env(int robot, const vmv_env *env, const float *d_q, size_t n, uint64_t *d_bits, void *stream)
+    {
+        if (!robot_ok(robot)) return VMV_ERR_UNKNOWN_ROBOT;
+        if (!env || !d_q || !d_bits) return VMV_ERR_INVALID_ARGUMENT;
+        if (!env->finalized) return VMV_ERR_NOT_FINALIZED;
+        if (n == 0) return VMV_OK;
+        return kLaunchers[robot]->validate(env->launch, d_q, n, d_bits, static_cast<hipStream_t>(stream), 1);
+    }
+
+    int vmv_validate_batch_self(int robot, const float *d_q, size_t n, uint64_t *d_bits, void *stream)
+    {
+        if (!robot_ok(robot)) return VMV_ERR_UNKNOWN_ROBOT;
+        if (!d_q || !d_bits) return VMV_ERR_INVALID_ARGUMENT;
+        if (n == 0) return VMV_OK;
+        return kLaunchers[robot]->validate(vmv::EnvLaunch{}, d_q, n, d_bits, static_cast<hipStream_t>(stream), 2);
     }
 
     int vmv_validate_motion_batch(int robot, const vmv_env *env, const float *d_a, const float *d_b, size_t n,

@@ -24,7 +24,8 @@ namespace vmv
     // status codes are the VMV_* values of include/vamp_mvt_amd.h
     struct RobotLaunchers
     {
-        int (*validate)(const EnvLaunch &, const float *d_q, size_t n, uint64_t *d_bits, hipStream_t);
+        // stage bit 1 = environment kernel (writes the words), bit 2 = self-collision kernel (ANDs into them)
+        int (*validate)(const EnvLaunch &, const float *d_q, size_t n, uint64_t *d_bits, hipStream_t, int stages);
         int (*validate_motion)(const EnvLaunch &, const float *d_a, const float *d_b, size_t n, uint64_t *d_bits,
                                hipStream_t);
         int (*fk)(const float *d_q, size_t n, float *d_out, hipStream_t);
