@@ -71,6 +71,9 @@ def main():
     ap.add_argument("--configs", type=int, default=CONFIGS_PER_GPU, help="configurations per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=1 << 21)
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="development only: run the N-rank control flow with every rank on cuda:0 and the exchange "
+                         "over gloo (RCCL refuses two ranks on one device); never used for reported numbers")
     ap.add_argument("--env", default="shell64", choices=["shell64", "empty", "cage"],
                     help="diagnostics only: the metric is defined on shell64 (BASELINE config 2)")
     args = ap.parse_args()
@@ -84,11 +87,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if args.rehearse_on_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)  # RCCL
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)  # RCCL
 
     import vamp_mvt_amd as vamp
     from vamp_mvt_amd._lib import check, lib
@@ -129,7 +137,11 @@ def main():
         if evs is not None:
             evs[2].record(stream)
         if world > 1:
-            dist.all_gather_into_tensor(gathered, bits)
+            if args.rehearse_on_one_gpu:
+                parts = [torch.empty(words, dtype=torch.int64) for _ in range(world)]
+                dist.all_gather(parts, bits.cpu())
+            else:
+                dist.all_gather_into_tensor(gathered, bits)
 
     for _ in range(args.warmup):
         step()
@@ -145,7 +157,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.rehearse_on_one_gpu else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     kernel_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in evs]))  # dominant kernel: environment half
