@@ -39,6 +39,8 @@ def spec_for(kind, robot="panda", seed=0):
             p2[2] += np.float32(rng.uniform(0.1, 0.5))
             spec.append(("capsule", capsule(p1, p2, rng.uniform(0.02, 0.08))))
         return spec
+    if kind == "many":  # more than 64 primitives per list: exercises the multi-chunk live-prefix count
+        return shell_spec(seed + 21, 150, 100, 0.35, 1.1)
     if kind == "capt":
         r_min, r_max = RADII[robot]
         spec = shell_spec(seed + 5, 4, 4)

@@ -8,6 +8,7 @@ from __future__ import annotations
 import ctypes
 import os
 import subprocess
+import sys
 
 import numpy as np
 
@@ -31,6 +32,10 @@ class CaptView(ctypes.Structure):
 def build_oracle():
     """Compile oracle/liboracle.so if missing or stale (gcc only; no GPU, no reference needed)."""
     so = os.path.join(ORACLE_DIR, "liboracle.so")
+    if not os.path.exists(os.path.join(ORACLE_DIR, "gen", "robots_gen.inc")):
+        # generated FK of the oracle (from the committed robot models; needs neither a GPU nor the reference)
+        subprocess.check_call([sys.executable, os.path.join(ORACLE_DIR, "..", "tools", "gen_code.py")],
+                              stdout=subprocess.DEVNULL)
     srcs = [os.path.join(ORACLE_DIR, f) for f in ("vamp_oracle.c", "vamp_oracle.h", "gen/robots_gen.inc")]
     if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["make", "-C", ORACLE_DIR, "liboracle.so"], stdout=subprocess.DEVNULL)

@@ -105,6 +105,21 @@ def test_edge_cases(vamp, oracle):
         p.validate_batch(q[:, :6], env)
 
 
+def test_large_primitive_lists_and_capacity(vamp, oracle):
+    env, oenv = make_env("many", oracle)
+    rid, q = uniform_configs(oracle, "panda", 8000, seed=4)
+    assert np.array_equal(vamp.panda.validate_batch(q, env), oracle.validate_batch(rid, oenv, q, threads=8))
+    a, b = q[:800], q[800:1600]
+    assert np.array_equal(vamp.panda.validate_motion_batch(a, b, env), oracle.validate_motion_batch(rid, oenv, a, b))
+    # more primitive records than the 48 KiB on-chip staging budget: a status code, not a crash or a fallback
+    big = vamp.Environment()
+    for i in range(2000):
+        big.add_sphere(vamp.Sphere([2.0 + 0.01 * i, 0.0, 0.0], 0.01))
+    with pytest.raises(vamp.VmvError) as ei:
+        vamp.panda.validate_batch(q[:64], big)
+    assert ei.value.status == 4  # VMV_ERR_CAPACITY
+
+
 def test_environment_rebuild_after_mutation(vamp, oracle):
     env, oenv = make_env("cage", oracle)
     rid, q = uniform_configs(oracle, "panda", 4000, seed=2)

@@ -175,7 +175,7 @@ namespace vmv
     {
         env_cptr dev;              // device memory, wave-uniform (scalar loads)
         lds_cptr lds;              // primitive block in LDS
-        const float *capt0_tests;  // split planes of point cloud 0: LDS copy when staged, else dev->capt[0].tests
+        uint32_t capt0_planes_in_lds;  // how many leading split planes of point cloud 0 sit in LDS behind the block
     };
 
     // collision/math.hh:10-42
@@ -200,8 +200,12 @@ namespace vmv
     // CAPT::collides_simd (collision/capt.hh:428-512), one lane.  The reference's `inbounds.none()` early
     // returns do not change any lane's answer, so a lane's result is independent of its rake neighbours.
     __device__ __forceinline__ bool
-    capt_collides(env_cptr D, const uint32_t ci, const float *tests, float x, float y, float z, float r, bool active)
+    capt_collides(env_cptr D, const uint32_t ci, lds_cptr planes_lds, const uint32_t n_lds, float x, float y, float z,
+                  float r, bool active)
     {
+        // the top levels of the tree are staged in LDS (planes_lds[0 .. n_lds)); deeper planes come through L1/L2
+        const gf_cptr planes = (gf_cptr) D->capt[ci].tests;
+        auto plane = [&](const uint32_t i) -> float { return (i < n_lds) ? planes_lds[i] : planes[i]; };
         bool inb = active;
         inb = inb && (x + r >= D->capt[ci].aabb_top[0]) && (x - r <= D->capt[ci].aabb_top[3]);
         inb = inb && (y + r >= D->capt[ci].aabb_top[1]) && (y - r <= D->capt[ci].aabb_top[4]);
@@ -209,12 +213,12 @@ namespace vmv
         if (!wave_any(inb)) return false;
 
         const uint32_t nlog2 = D->capt[ci].nlog2;
-        uint32_t idx = (uint32_t) (x >= tests[0]) + 1u;
+        uint32_t idx = (uint32_t) (x >= plane(0)) + 1u;
         uint32_t k = 1;
         for (uint32_t i = 1; i < nlog2; ++i)
         {
             const float ck = (k == 0) ? x : (k == 1) ? y : z;
-            idx = (idx << 1) + (uint32_t) (ck >= tests[idx]) + 1u;
+            idx = (idx << 1) + (uint32_t) (ck >= plane(idx)) + 1u;
             k = (k == 2) ? 0 : k + 1;
         }
         const uint32_t zi = idx - D->capt[ci].n_tests;
@@ -268,7 +272,6 @@ namespace vmv
         const uint32_t lo = uniform((uint32_t) v), hi = uniform((uint32_t) (v >> 32));
         return ((uint64_t) hi << 32) | lo;
     }
-    __device__ __forceinline__ const float *uniform(const float *p) { return (const float *) uniform((uint64_t) p); }
     __device__ __forceinline__ env_cptr uniform(env_cptr p) { return (env_cptr) uniform((uint64_t) p); }
     __device__ __forceinline__ lds_cptr uniform(lds_cptr p)
     {
@@ -441,8 +444,7 @@ namespace vmv
         {
             const bool act = active && !hit;
             if (!wave_any(act)) break;
-            const float *tests = (ci == 0) ? E.capt0_tests : (const float *) D.capt[ci].tests;
-            hit |= capt_collides(Dp, ci, tests, x, y, z, r, act);
+            hit |= capt_collides(Dp, ci, E.lds + D.n_floats, (ci == 0) ? E.capt0_planes_in_lds : 0u, x, y, z, r, act);
         }
         return hit;
 #undef D
@@ -480,7 +482,7 @@ namespace vmv
     env_gate(const EnvView E_, lds_cptr slab, lds_ptr scratch_, const int radius_index_, const bool active)
     {
         const uint32_t lane = __lane_id();
-        const EnvView E{uniform(E_.dev), uniform(E_.lds), uniform(E_.capt0_tests)};
+        const EnvView E{uniform(E_.dev), uniform(E_.lds), uniform(E_.capt0_planes_in_lds)};
         lds_u32 *list = (lds_u32 *) uniform((lds_cptr) scratch_);
         const bool gate = group_any<G>(
             env_hit<G>(E, slab[0], slab[kWave], slab[2 * kWave], Tab::radius(uniform(radius_index_)), active));
@@ -497,7 +499,7 @@ namespace vmv
     env_fine(const EnvView E_, lds_cptr slab, lds_ptr scratch_, const int n_fine_, const int radii_offset_)
     {
         const uint32_t lane = __lane_id();
-        const EnvView E{uniform(E_.dev), uniform(E_.lds), uniform(E_.capt0_tests)};
+        const EnvView E{uniform(E_.dev), uniform(E_.lds), uniform(E_.capt0_planes_in_lds)};
         lds_u32 *list = (lds_u32 *) uniform((lds_cptr) scratch_);
         lds_u32 *flags = list + kWave;
         const int n_fine = uniform(n_fine_), radii_offset = uniform(radii_offset_);
