@@ -33,27 +33,28 @@ def flit(v: float) -> str:
     return float.hex(f) + "f"
 
 
-def op_expr(op, a, b, sin="vmv::vsin", cos="vmv::vcos"):
+def op_expr(op, a, b, sin="vmv::vsin", cos="vmv::vcos", qname="q", prefix="t"):
+    t = prefix
     if op == "in":
-        return f"q[{a}]"
+        return f"{qname}[{a}]"
     if op == "sin":
-        return f"{sin}(t{a})"
+        return f"{sin}({t}{a})"
     if op == "cos":
-        return f"{cos}(t{a})"
+        return f"{cos}({t}{a})"
     if op == "neg":
-        return f"-t{a}"
+        return f"-{t}{a}"
     if op == "const":
         return flit(a)
     if op == "mul":
-        return f"t{a} * t{b}"
+        return f"{t}{a} * {t}{b}"
     if op == "add":
-        return f"t{a} + t{b}"
+        return f"{t}{a} + {t}{b}"
     if op == "sub":
-        return f"t{a} - t{b}"
+        return f"{t}{a} - {t}{b}"
     if op == "cmul":
-        return f"{flit(a)} * t{b}"
+        return f"{flit(a)} * {t}{b}"
     if op == "cadd":
-        return f"{flit(a)} + t{b}"
+        return f"{flit(a)} + {t}{b}"
     raise ValueError(op)
 
 
@@ -68,11 +69,12 @@ def deps(op, a, b):
 
 
 class Emitter:
-    def __init__(self, m):
+    def __init__(self, m, qname="q", prefix="t", indent="        "):
         self.m = m
         self.ops = m["ops"]
         self.done = [False] * len(self.ops)
         self.lines = []
+        self.qname, self.prefix, self.indent = qname, prefix, indent
 
     def need(self, spheres):
         """Emit (in tape order) every not-yet-emitted op the given spheres depend on."""
@@ -86,12 +88,13 @@ class Emitter:
             stack += deps(*self.ops[i])
         for i in sorted(want):
             op, a, b = self.ops[i]
-            self.lines.append(f"        const float t{i} = {op_expr(op, a, b)};")
+            self.lines.append(f"{self.indent}const float {self.prefix}{i} = "
+                              f"{op_expr(op, a, b, qname=self.qname, prefix=self.prefix)};")
             self.done[i] = True
 
     def coord(self, s, k):
         kind, v = self.m["outputs"][s][k]
-        return f"t{v}" if kind == "op" else flit(v)
+        return f"{self.prefix}{v}" if kind == "op" else flit(v)
 
 
 def f32(x):
@@ -182,32 +185,59 @@ def emit_robot(m):
     L.append("")
 
     # ---- self-collision half of fkcc -----------------------------------------------------------------------
-    a_side = sorted({s for sg in m["self_groups"] for s in {p[0] for p in sg["pairs"]} | {sg["bound_a"]}})
-    dealt = len(a_side) <= SELF_DEAL_MAX_A
+    # Groups (A, B) are handled in passes: each pass keeps the spheres of a batch of A links in registers (at most
+    # SELF_DEAL_MAX_A spheres) and walks the chain once, so robots whose A side does not fit run several passes
+    # (FK is recomputed per pass; it is cheap next to spilling).
+    a_links = [ln for ln in links if any(sg["a"] == ln for sg in m["self_groups"])]
+    link_size = {ln: 1 + len(env_by_link[ln]["fine"]) for ln in links}
+    batches, cur, cur_n = [], [], 0
+    for ln in a_links:
+        if cur and cur_n + link_size[ln] > SELF_DEAL_MAX_A:
+            batches.append(cur)
+            cur, cur_n = [], 0
+        cur.append(ln)
+        cur_n += link_size[ln]
+    if cur:
+        batches.append(cur)
     L.append("    // Self-collision half of Robot::fkcc<rake> (\"robot self-collisions\").")
-    if dealt:
-        L.append("    // Groups (A, B) run when B is the current link.  Gates (bounding pair) are per lane; the fine pairs of the")
-        L.append("    // few rakes whose gate fired are re-dealt over the 64 lanes as (passing lane, B sphere) items: B's")
-        L.append("    // sphere comes from the LDS slab column of the lane the item belongs to, A's spheres from that lane's")
-        L.append("    // registers through ds_bpermute (__shfl); hits return through LDS flags.")
-        L.append("    template <int G>")
-        L.append("    __device__ __forceinline__ bool fkcc_self(const float (&q)[kDim], vmv::lds_ptr slab, const bool skip)")
-        L.append("    {")
-        L.append("        bool bad = skip;")
-        L.append("        const unsigned lane = __lane_id();")
-        L.append("        const vmv::lds_cptr wave_slab = vmv::uniform((vmv::lds_cptr) (slab - lane));")
-        L.append("        vmv::lds_u32 *const list = (vmv::lds_u32 *) (slab - lane + kSlabSpheres * 3 * vmv::kWave);")
-        L.append("        vmv::lds_u32 *const flags = list + vmv::kWave;")
-        em = Emitter(m)
+    L.append("    // Groups (A, B) run when B is the current link.  Gates (bounding pair) are per lane; the fine pairs of the")
+    L.append("    // few rakes whose gate fired are re-dealt over the 64 lanes as (passing lane, B sphere) items: B's")
+    L.append("    // sphere comes from the LDS slab column of the lane the item belongs to, A's spheres from that lane's")
+    L.append("    // registers through ds_bpermute (__shfl); hits return through LDS flags.")
+    L.append(f"    // {len(batches)} pass(es) over the chain; each keeps one batch of A links in registers.")
+    L.append("    template <int G>")
+    L.append("    __device__ __forceinline__ bool fkcc_self(const float (&q)[kDim], vmv::lds_ptr slab, const bool skip)")
+    L.append("    {")
+    L.append("        bool bad = skip;")
+    L.append("        const unsigned lane = __lane_id();")
+    L.append("        const vmv::lds_cptr wave_slab = vmv::uniform((vmv::lds_cptr) (slab - lane));")
+    L.append("        vmv::lds_u32 *const list = (vmv::lds_u32 *) (slab - lane + kSlabSpheres * 3 * vmv::kWave);")
+    L.append("        vmv::lds_u32 *const flags = list + vmv::kWave;")
+    for bi, batch in enumerate(batches):
+        batch_set = set(batch)
+        L.append(f"        {{  // pass {bi}: A in {{{', '.join(batch)}}}")
+        qn = "q"
+        if len(batches) > 1:
+            # an opaque copy of the configuration keeps the compiler from merging the passes' FK back together
+            L.append("            float qp[kDim];")
+            L.append("#pragma unroll")
+            L.append("            for (int j = 0; j < kDim; ++j)")
+            L.append("            {")
+            L.append("                qp[j] = q[j];")
+            L.append('                asm volatile("" : "+v"(qp[j]));')
+            L.append("            }")
+            qn = "qp"
+        em = Emitter(m, qname=qn, prefix=f"p{bi}_", indent="            ")
+        I = "            "
         for ln in links:
-            groups = self_by_b.get(ln, [])
+            groups = [sg for sg in self_by_b.get(ln, []) if sg["a"] in batch_set]
             if not groups:
                 continue
             g_env = env_by_link[ln]
             fine = g_env["fine"]
             bb = g_env["bound"]
             chunks = [fine[i:i + CHUNK] for i in range(0, len(fine), CHUNK)]
-            em.lines.append(f"        // ---- B = {ln}: {len(fine)} spheres, {len(groups)} group(s)")
+            em.lines.append(f"{I}// ---- B = {ln}: {len(fine)} spheres, {len(groups)} group(s)")
             for sg in groups:
                 em.need(sorted({p[0] for p in sg["pairs"]}) + [sg["bound_a"]])
             em.need([bb] + fine)
@@ -215,93 +245,63 @@ def emit_robot(m):
             for gi, sg in enumerate(groups):
                 ba = sg["bound_a"]
                 rs = f32(f32(radii[ba]) + f32(radii[bb]))
-                gn = f"gate_{links.index(ln)}_{gi}"
+                gn = f"gate_{bi}_{links.index(ln)}_{gi}"
                 gate_names.append(gn)
                 em.lines.append(
-                    f"        const bool {gn} = vmv::group_any<G>(vmv::neg(vmv::sql2_3({em.coord(ba, 0)}, {em.coord(ba, 1)}, "
+                    f"{I}const bool {gn} = vmv::group_any<G>(vmv::neg(vmv::sql2_3({em.coord(ba, 0)}, {em.coord(ba, 1)}, "
                     f"{em.coord(ba, 2)}, {em.coord(bb, 0)}, {em.coord(bb, 1)}, {em.coord(bb, 2)}) - {flit(float(f32(rs * rs)))}))"
                     f" && !bad;  // {sg['a']} vs. {ln}")
-            em.lines.append("        if (vmv::wave_any(" + " || ".join(gate_names) + "))")
-            em.lines.append("        {")
-            em.lines.append("            flags[lane] = 0u;")
+            em.lines.append(f"{I}if (vmv::wave_any(" + " || ".join(gate_names) + "))")
+            em.lines.append(f"{I}{{")
+            em.lines.append(f"{I}    flags[lane] = 0u;")
             done = 0
             for ci, ch in enumerate(chunks):
                 for si, s in enumerate(ch):
                     for k in range(3):
-                        em.lines.append(f"            slab[{3 * si + k} * vmv::kWave] = {em.coord(s, k)};")
-                em.lines.append("            vmv::wave_lds_sync();")
+                        em.lines.append(f"{I}    slab[{3 * si + k} * vmv::kWave] = {em.coord(s, k)};")
+                em.lines.append(f"{I}    vmv::wave_lds_sync();")
                 for gi, sg in enumerate(groups):
                     a_sph = sorted({p[0] for p in sg["pairs"]})
                     b_sph = sorted({p[1] for p in sg["pairs"]})
                     assert b_sph == fine and sg["pairs"] == [[s, t] for s in a_sph for t in b_sph]
-                    em.lines.append(f"            if (vmv::wave_any({gate_names[gi]}))  // {sg['a']} vs. {ln}, chunk {ci}")
-                    em.lines.append("            {")
-                    em.lines.append(f"                const int k = vmv::deal_list(list, {gate_names[gi]});")
-                    em.lines.append(f"                const int items = k * {len(ch)};")
-                    em.lines.append("                const float inv_k = 1.0f / (float) k;")
-                    em.lines.append("                for (int base = 0; base < items; base += vmv::kWave)")
-                    em.lines.append("                {")
-                    em.lines.append("                    const int i = base + (int) lane;")
-                    em.lines.append("                    const bool act = i < items;")
-                    em.lines.append("                    const int t = act ? (int) (((float) i + 0.5f) * inv_k) : 0;")
-                    em.lines.append("                    const int j = act ? (i - t * k) : 0;")
-                    em.lines.append("                    const unsigned src = list[j];")
-                    em.lines.append("                    const vmv::lds_cptr p = wave_slab + 3 * t * vmv::kWave + src;")
-                    em.lines.append("                    const float bx = p[0], by = p[vmv::kWave], bz = p[2 * vmv::kWave];")
-                    em.lines.append(f"                    const float rb = kRadii[{radii_off[ln] + 1 + done} + t];")
-                    em.lines.append("                    bool h = false;")
+                    J = I + "    "
+                    em.lines.append(f"{J}if (vmv::wave_any({gate_names[gi]}))  // {sg['a']} vs. {ln}, chunk {ci}")
+                    em.lines.append(f"{J}{{")
+                    em.lines.append(f"{J}    const int k = vmv::deal_list(list, {gate_names[gi]});")
+                    em.lines.append(f"{J}    const int items = k * {len(ch)};")
+                    em.lines.append(f"{J}    const float inv_k = 1.0f / (float) k;")
+                    em.lines.append(f"{J}    for (int base = 0; base < items; base += vmv::kWave)")
+                    em.lines.append(f"{J}    {{")
+                    em.lines.append(f"{J}        const int i = base + (int) lane;")
+                    em.lines.append(f"{J}        const bool act = i < items;")
+                    em.lines.append(f"{J}        const int t = act ? (int) (((float) i + 0.5f) * inv_k) : 0;")
+                    em.lines.append(f"{J}        const int j = act ? (i - t * k) : 0;")
+                    em.lines.append(f"{J}        const unsigned src = list[j];")
+                    em.lines.append(f"{J}        const vmv::lds_cptr p = wave_slab + 3 * t * vmv::kWave + src;")
+                    em.lines.append(f"{J}        const float bx = p[0], by = p[vmv::kWave], bz = p[2 * vmv::kWave];")
+                    em.lines.append(f"{J}        const float rb = kRadii[{radii_off[ln] + 1 + done} + t];")
+                    em.lines.append(f"{J}        bool h = false;")
                     for s in a_sph:
                         cs = []
                         for k in range(3):
                             kind, v = m["outputs"][s][k]
-                            cs.append(f"__shfl(t{v}, (int) src)" if kind == "op" else flit(v))
-                        em.lines.append("                    {")
-                        em.lines.append(f"                        const float rs = {flit(radii[s])} + rb;")
-                        em.lines.append(f"                        h |= vmv::neg(vmv::sql2_3({cs[0]}, {cs[1]}, {cs[2]}, bx, by, bz) - rs * rs);")
-                        em.lines.append("                    }")
-                    em.lines.append("                    if (h && act) flags[src] = 1u;")
-                    em.lines.append("                }")
-                    em.lines.append("                vmv::wave_lds_sync();")
-                    em.lines.append("            }")
+                            cs.append(f"__shfl({em.prefix}{v}, (int) src)" if kind == "op" else flit(v))
+                        em.lines.append(f"{J}        {{")
+                        em.lines.append(f"{J}            const float rs = {flit(radii[s])} + rb;")
+                        em.lines.append(f"{J}            h |= vmv::neg(vmv::sql2_3({cs[0]}, {cs[1]}, {cs[2]}, bx, by, bz) - rs * rs);")
+                        em.lines.append(f"{J}        }}")
+                    em.lines.append(f"{J}        if (h && act) flags[src] = 1u;")
+                    em.lines.append(f"{J}    }}")
+                    em.lines.append(f"{J}    vmv::wave_lds_sync();")
+                    em.lines.append(f"{J}}}")
                 done += len(ch)
-            em.lines.append("            bad |= vmv::group_any<G>(flags[lane] != 0u);")
-            em.lines.append("        }")
+            em.lines.append(f"{I}    bad |= vmv::group_any<G>(flags[lane] != 0u);")
+            em.lines.append(f"{I}}}")
         L += em.lines
-        L.append("        return bad;")
-        L.append("    }")
-    else:
-        L.append("    // (A side too large for registers + shuffles: fully unrolled form on registers.)")
-        L.append("    template <int G>")
-        L.append("    __device__ __forceinline__ bool fkcc_self(const float (&q)[kDim], vmv::lds_ptr, const bool skip)")
-        L.append("    {")
-        L.append("        bool bad = skip;")
-        em = Emitter(m)
-        for ln in links:
-            for sg in self_by_b.get(ln, []):
-                ba, bb = sg["bound_a"], sg["bound_b"]
-                a_sph = sorted({p[0] for p in sg["pairs"]})
-                b_sph = sorted({p[1] for p in sg["pairs"]})
-                em.need(a_sph + b_sph + [ba, bb])
-                rs = f32(f32(radii[ba]) + f32(radii[bb]))
-                em.lines.append(f"        {{  // {sg['a']} vs. {ln}")
-                em.lines.append(
-                    f"            const bool gate = vmv::group_any<G>(vmv::neg(vmv::sql2_3({em.coord(ba, 0)}, {em.coord(ba, 1)}, "
-                    f"{em.coord(ba, 2)}, {em.coord(bb, 0)}, {em.coord(bb, 1)}, {em.coord(bb, 2)}) - {flit(float(f32(rs * rs)))}));")
-                em.lines.append("            if (vmv::wave_any(gate && !bad))")
-                em.lines.append("            {")
-                em.lines.append("                bool h = false;")
-                for (sa, sb) in sg["pairs"]:
-                    rs = f32(f32(radii[sa]) + f32(radii[sb]))
-                    em.lines.append(
-                        f"                h |= vmv::neg(vmv::sql2_3({em.coord(sa, 0)}, {em.coord(sa, 1)}, {em.coord(sa, 2)}, "
-                        f"{em.coord(sb, 0)}, {em.coord(sb, 1)}, {em.coord(sb, 2)}) - {flit(float(f32(rs * rs)))});")
-                em.lines.append("                bad |= (gate && vmv::group_any<G>(h));")
-                em.lines.append("            }")
-                em.lines.append("        }")
-        L += em.lines
-        L.append("        return bad;")
-        L.append("    }")
-    L.append(f"    constexpr bool kSelfDealt = {'true' if dealt else 'false'};")
+        L.append("        }")
+    L.append("        return bad;")
+    L.append("    }")
+    L.append(f"    constexpr int kSelfPasses = {len(batches)};")
     L.append("")
 
     # ---- sphere_fk ----------------------------------------------------------------------------------------
