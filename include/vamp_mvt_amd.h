@@ -79,11 +79,23 @@ int vmv_env_add_capsule(vmv_env *env, const float *params8);
  * collision/capt.hh:296-369.  points: host pointer, [n][3] fp32. */
 int vmv_env_add_capt_pointcloud(vmv_env *env, const float *points_xyz, size_t n, float r_min, float r_max,
                                 float r_point, uint64_t *build_nanoseconds);
+/* Environment.add_mvt_pointcloud(points, r_min, r_max, workspace_aabb_min, workspace_aabb_max, r_point) -> build ns
+ * — environment.cc:164-177, collision/mvt.hh:147-170 (the fork's Multi-level Voxel Table).  Where the reference
+ * throws inside its noexcept constructor (a pool it sized up front runs out: mvt.hh:66-70, 634-648), this returns
+ * VMV_ERR_CAPACITY and `*reason` (may be NULL) = 1 voxel capacity, 2 point pool (> 10 % of the voxels occupied),
+ * 3 z-table pool (> 50 % of the (x, y) columns occupied), 4 degenerate grid, 5 grid too large for the dense table. */
+int vmv_env_add_mvt_pointcloud(vmv_env *env, const float *points_xyz, size_t n, float r_min, float r_max,
+                               const float *workspace_min3, const float *workspace_max3, float r_point,
+                               uint64_t *build_nanoseconds, int *reason);
 /* Sorts every primitive list by min_distance (collision/environment.hh:46-72) and uploads the environment to
  * the current device.  The reference re-sorts on every add and converts per call (robot_helper.hh:266). */
 int vmv_env_finalize(vmv_env *env);
-/* counts[6]: spheres, capsules, z_capsules, cuboids, z_cuboids, capt point clouds */
+/* counts[6]: spheres, capsules, z_capsules, cuboids, z_cuboids, capt point clouds; vmv_env_mvt_count: MVT clouds */
 int vmv_env_counts(const vmv_env *env, size_t *counts6);
+int vmv_env_mvt_count(const vmv_env *env, size_t *count);
+/* MVT cloud `index`: grid_width, per-voxel capacity, occupied voxels, inverse scale factor, global box (6 floats) */
+int vmv_env_mvt_info(const vmv_env *env, size_t index, uint32_t *grid_width, uint32_t *capacity, uint32_t *n_voxels,
+                     float *inverse_scale_factor, float *global_box6);
 /* sorted host copies for inspection: spheres [n][5] (x y z r min_distance), cuboids [n][16], capsules [n][9] */
 int vmv_env_get_spheres(const vmv_env *env, float *out, size_t capacity, size_t *n);
 int vmv_env_get_cuboids(const vmv_env *env, int z_aligned, float *out, size_t capacity, size_t *n);
@@ -115,6 +127,13 @@ int vmv_fk_batch_host(int robot, const float *q, size_t n, float *out);
 int vmv_validate_batch_host(int robot, const vmv_env *env, const float *q, size_t n, uint64_t *bits);
 int vmv_validate_motion_batch_host(int robot, const vmv_env *env, const float *start, const float *goal, size_t n,
                                    uint64_t *bits);
+
+/* ---- sampler --------------------------------------------------------------------------------------------- */
+/* <robot>.halton() / RNG.next() — random/halton.hh:75-108 with the default prime bases, generated on the device:
+ * fills d_q[n][dimension] with samples skip+1 .. skip+n of the reference's sequence (bit-exact: the sequence's
+ * n/d are exact small integers, so element j of sample i is float(radical_inverse_numerator) / float(b_j^k),
+ * scaled by Robot::scale_configuration).  Valid while skip + n <= 1,000,000 (the reference re-seeds after that). */
+int vmv_halton_configs(int robot, uint64_t skip, float *d_q, size_t n, void *stream);
 
 /* ---- measurement support (bench.py) ---------------------------------------------------------------------- */
 /* Runs vmv_validate_batch `iters` times on `stream` between two HIP events recorded on that same stream and

@@ -151,6 +151,23 @@ typedef struct
     float r_min, r_max, r_point;
 } vo_capt;
 
+/* collision/mvt.hh: the three-level table (x -> y tables -> z tables -> voxel index) flattened to index arrays */
+#define VO_MVT_INVALID 0xffffffffu
+typedef struct
+{
+    float r_min, r_max, r_point;
+    float ws_min[3], ws_max[3], gmin[3], gmax[3];
+    float inv_scale;
+    uint32_t grid_width, cap;
+    uint32_t *x_table;  /* [grid_width] */
+    uint32_t *y_tables; /* [n_y][grid_width] */
+    uint32_t *z_tables; /* [n_z][grid_width] */
+    uint32_t n_y, n_z, n_vox;
+    float *bbox; /* [n_vox][6] */
+    uint32_t *count;
+    float *px, *py, *pz; /* [n_vox][cap], +inf padded (mvt.hh:650) */
+} vo_mvt;
+
 struct vo_env
 {
     vo_sphere *spheres;
@@ -165,6 +182,8 @@ struct vo_env
     size_t n_z_cuboids;
     vo_capt *capts;
     size_t n_capts;
+    vo_mvt *mvts;
+    size_t n_mvts;
 };
 
 vo_env *vo_env_create(void) { return (vo_env *) calloc(1, sizeof(vo_env)); }
@@ -179,6 +198,18 @@ static void capt_free(vo_capt *c)
     free(c->aff[2]);
 }
 
+static void mvt_free(vo_mvt *m)
+{
+    free(m->x_table);
+    free(m->y_tables);
+    free(m->z_tables);
+    free(m->bbox);
+    free(m->count);
+    free(m->px);
+    free(m->py);
+    free(m->pz);
+}
+
 void vo_env_destroy(vo_env *e)
 {
     if (!e) return;
@@ -189,6 +220,8 @@ void vo_env_destroy(vo_env *e)
     free(e->z_cuboids);
     for (size_t i = 0; i < e->n_capts; ++i) capt_free(&e->capts[i]);
     free(e->capts);
+    for (size_t i = 0; i < e->n_mvts; ++i) mvt_free(&e->mvts[i]);
+    free(e->mvts);
     free(e);
 }
 
@@ -670,6 +703,251 @@ int vo_capt_collides_simd(const vo_env *e, size_t index, const float *cx, const 
 }
 
 /* ------------------------------------------------------------------------- */
+/* MVT build + query (collision/mvt.hh)                                       */
+/* ------------------------------------------------------------------------- */
+
+/* mvt.hh:754-764 */
+static unsigned next_power_of_two(unsigned n)
+{
+    if (n == 0) return 1;
+    n--;
+    n |= n >> 1;
+    n |= n >> 2;
+    n |= n >> 4;
+    n |= n >> 8;
+    n |= n >> 16;
+    n++;
+    return n;
+}
+
+int vo_env_add_mvt(vo_env *e, const float *pts, size_t n, float r_min, float r_max, const float *ws_min,
+                   const float *ws_max, float r_point)
+{
+    vo_mvt m;
+    memset(&m, 0, sizeof(m));
+    m.r_min = r_min;
+    m.r_max = r_max;
+    m.r_point = r_point;
+    memcpy(m.ws_min, ws_min, 12);
+    memcpy(m.ws_max, ws_max, 12);
+    /* configure_grid (mvt.hh:438-447) */
+    const float workspace_width = ws_max[0] - ws_min[0];
+    const float cells = floorf(workspace_width / r_max);
+    if (!(cells >= 1.0f) || n == 0) return 4;
+    const uint32_t gw32 = (cells >= 4294967296.0f) ? 0xffffffffu : (uint32_t) cells;
+    m.grid_width = gw32 < 65535u ? gw32 : 65535u;
+    m.inv_scale = (float) m.grid_width / workspace_width;
+    const uint32_t gw = m.grid_width;
+    /* initialize_point_coord_pool (mvt.hh:455-477) */
+    size_t est = (size_t) pow((double) r_max / 0.02, (double) 3.0f);
+    unsigned bytes = next_power_of_two((unsigned) est * (unsigned) sizeof(float));
+    if (bytes < VO_RAKE * sizeof(float)) bytes = VO_RAKE * sizeof(float);
+    const size_t pool_bytes = (size_t) ((double) ((size_t) gw * gw * gw) * 0.1 * (double) (size_t) bytes * 3);
+    const size_t pool_floats = pool_bytes / sizeof(float);
+    m.cap = bytes / (unsigned) sizeof(float);
+    const size_t max_voxels = pool_floats / (3 * (size_t) m.cap);
+    /* initialize_voxel_index_pool (mvt.hh:494-508): room for grid_width^2 / 2 z-tables */
+    const size_t max_z_tables = (size_t) ((double) ((size_t) gw * gw) * 0.5);
+
+    m.x_table = (uint32_t *) malloc(gw * sizeof(uint32_t));
+    for (uint32_t i = 0; i < gw; ++i) m.x_table[i] = VO_MVT_INVALID;
+    size_t cap_y = 0, cap_z = 0, cap_v = 0;
+    int rc = 0;
+    /* build_spatial_grid (mvt.hh:530-593) */
+    for (size_t i = 0; i < n && rc == 0; ++i)
+    {
+        const float *p = pts + 3 * i;
+        uint32_t v[3];
+        for (int k = 0; k < 3; ++k)
+        {
+            const float f = (p[k] - ws_min[k]) * m.inv_scale;
+            const float c = stdclamp(f, 0.0f, (float) (gw - 1));
+            v[k] = (uint32_t) (uint16_t) c;
+        }
+        uint32_t yt = m.x_table[v[0]];
+        if (yt == VO_MVT_INVALID)
+        {
+            if (m.n_y == cap_y)
+            {
+                cap_y = cap_y ? cap_y * 2 : 16;
+                m.y_tables = (uint32_t *) realloc(m.y_tables, cap_y * gw * sizeof(uint32_t));
+            }
+            yt = m.n_y++;
+            for (uint32_t j = 0; j < gw; ++j) m.y_tables[(size_t) yt * gw + j] = VO_MVT_INVALID;
+            m.x_table[v[0]] = yt;
+        }
+        uint32_t zt = m.y_tables[(size_t) yt * gw + v[1]];
+        if (zt == VO_MVT_INVALID)
+        {
+            if (m.n_z + 1 > max_z_tables)
+            {
+                rc = 3;
+                break;
+            }
+            if (m.n_z == cap_z)
+            {
+                cap_z = cap_z ? cap_z * 2 : 64;
+                m.z_tables = (uint32_t *) realloc(m.z_tables, cap_z * gw * sizeof(uint32_t));
+            }
+            zt = m.n_z++;
+            for (uint32_t j = 0; j < gw; ++j) m.z_tables[(size_t) zt * gw + j] = VO_MVT_INVALID;
+            m.y_tables[(size_t) yt * gw + v[1]] = zt;
+        }
+        uint32_t vi = m.z_tables[(size_t) zt * gw + v[2]];
+        if (vi == VO_MVT_INVALID)
+        {
+            if ((size_t) m.n_vox + 1 > max_voxels)
+            {
+                rc = 2;
+                break;
+            }
+            if (m.n_vox == cap_v)
+            {
+                cap_v = cap_v ? cap_v * 2 : 256;
+                m.bbox = (float *) realloc(m.bbox, cap_v * 6 * sizeof(float));
+                m.count = (uint32_t *) realloc(m.count, cap_v * sizeof(uint32_t));
+                m.px = (float *) realloc(m.px, cap_v * m.cap * sizeof(float));
+                m.py = (float *) realloc(m.py, cap_v * m.cap * sizeof(float));
+                m.pz = (float *) realloc(m.pz, cap_v * m.cap * sizeof(float));
+            }
+            vi = m.n_vox++;
+            m.count[vi] = 0;
+            for (uint32_t j = 0; j < m.cap; ++j)
+                m.px[(size_t) vi * m.cap + j] = m.py[(size_t) vi * m.cap + j] = m.pz[(size_t) vi * m.cap + j] = INFINITY;
+            m.z_tables[(size_t) zt * gw + v[2]] = vi;
+        }
+        if (m.count[vi] >= m.cap)
+        {
+            rc = 1;
+            break;
+        }
+        const uint32_t c = m.count[vi];
+        m.px[(size_t) vi * m.cap + c] = p[0];
+        m.py[(size_t) vi * m.cap + c] = p[1];
+        m.pz[(size_t) vi * m.cap + c] = p[2];
+        float *bb = m.bbox + 6 * (size_t) vi;
+        if (c == 0)
+        {
+            memcpy(bb, p, 12);
+            memcpy(bb + 3, p, 12);
+        }
+        else
+            for (int k = 0; k < 3; ++k)
+            {
+                bb[k] = fminf(bb[k], p[k]);
+                bb[3 + k] = fmaxf(bb[3 + k], p[k]);
+            }
+        m.count[vi] = c + 1;
+    }
+    if (rc != 0)
+    {
+        mvt_free(&m);
+        return rc;
+    }
+    /* compute_global_bounds (mvt.hh:595-609) */
+    for (int k = 0; k < 3; ++k)
+    {
+        m.gmin[k] = 3.402823466e+38f;
+        m.gmax[k] = -3.402823466e+38f;
+    }
+    for (uint32_t vi = 0; vi < m.n_vox; ++vi)
+        for (int k = 0; k < 3; ++k)
+        {
+            m.gmin[k] = fminf(m.gmin[k], m.bbox[6 * (size_t) vi + k]);
+            m.gmax[k] = fmaxf(m.gmax[k], m.bbox[6 * (size_t) vi + 3 + k]);
+        }
+    e->mvts = (vo_mvt *) realloc(e->mvts, (e->n_mvts + 1) * sizeof(vo_mvt));
+    e->mvts[e->n_mvts++] = m;
+    return 0;
+}
+
+int vo_env_mvt_view(const vo_env *e, size_t index, vo_mvt_view *out)
+{
+    if (index >= e->n_mvts) return -1;
+    const vo_mvt *m = &e->mvts[index];
+    out->grid_width = m->grid_width;
+    out->capacity = m->cap;
+    out->n_voxels = m->n_vox;
+    out->n_y_tables = m->n_y;
+    out->n_z_tables = m->n_z;
+    out->inverse_scale_factor = m->inv_scale;
+    memcpy(out->global_min, m->gmin, 12);
+    memcpy(out->global_max, m->gmax, 12);
+    out->x_table = m->x_table;
+    out->y_tables = m->y_tables;
+    out->z_tables = m->z_tables;
+    out->voxel_count = m->count;
+    out->voxel_bbox = m->bbox;
+    out->px = m->px;
+    out->py = m->py;
+    out->pz = m->pz;
+    return 0;
+}
+
+/* MVT::collides (mvt.hh:204-279) == one lane of collides_simd (mvt.hh:282-403; the 8-point SIMD chunks read the
+ * voxel's +inf padding, which never collides).  Float -> uint16 casts are applied to in-range values exactly as
+ * written; where the reference's cast would be undefined (negative upper bound) the range is empty here. */
+static int mvt_collides_lane(const vo_mvt *m, float cx, float cy, float cz, float radius)
+{
+    const float c[3] = {cx, cy, cz};
+    const float qr = radius + m->r_point;
+    const float qr2 = qr * qr;
+    for (int k = 0; k < 3; ++k)
+        if (c[k] + qr < m->gmin[k] || c[k] - qr > m->gmax[k]) return 0;
+    const float gqr = fminf(1.0f, qr * m->inv_scale);
+    int lo[3], hi[3];
+    for (int k = 0; k < 3; ++k)
+    {
+        const float g = (c[k] - m->ws_min[k]) * m->inv_scale;
+        const float a = fmaxf(0.0f, g - gqr);
+        const float b = fminf((float) (m->grid_width - 1), g + gqr);
+        if (b < 0.0f) return 0;
+        lo[k] = (int) (uint16_t) a;
+        hi[k] = (int) (uint16_t) b;
+    }
+    const uint32_t gw = m->grid_width;
+    for (int vx = lo[0]; vx <= hi[0]; ++vx)
+    {
+        const uint32_t yt = m->x_table[vx];
+        if (yt == VO_MVT_INVALID) continue;
+        for (int vy = lo[1]; vy <= hi[1]; ++vy)
+        {
+            const uint32_t zt = m->y_tables[(size_t) yt * gw + vy];
+            if (zt == VO_MVT_INVALID) continue;
+            for (int vz = lo[2]; vz <= hi[2]; ++vz)
+            {
+                const uint32_t vi = m->z_tables[(size_t) zt * gw + vz];
+                if (vi == VO_MVT_INVALID) continue;
+                const float *bb = m->bbox + 6 * (size_t) vi;
+                if (c[0] + qr < bb[0] || c[0] - qr > bb[3] || c[1] + qr < bb[1] || c[1] - qr > bb[4] ||
+                    c[2] + qr < bb[2] || c[2] - qr > bb[5])
+                    continue;
+                const float *x = m->px + (size_t) vi * m->cap, *y = m->py + (size_t) vi * m->cap,
+                            *z = m->pz + (size_t) vi * m->cap;
+                for (uint32_t i = 0; i < m->count[vi]; ++i)
+                {
+                    const float dx = c[0] - x[i], dy = c[1] - y[i], dz = c[2] - z[i];
+                    if (dx * dx + dy * dy + dz * dz <= qr2) return 1;
+                }
+            }
+        }
+    }
+    return 0;
+}
+
+int vo_mvt_collides(const vo_env *e, size_t index, const float c[3], float r)
+{
+    return mvt_collides_lane(&e->mvts[index], c[0], c[1], c[2], r);
+}
+int vo_mvt_collides_simd(const vo_env *e, size_t index, const float *cx, const float *cy, const float *cz,
+                         const float *r, int lanes)
+{
+    for (int l = 0; l < lanes; ++l)
+        if (mvt_collides_lane(&e->mvts[index], cx[l], cy[l], cz[l], r[l])) return 1;
+    return 0;
+}
+
+/* ------------------------------------------------------------------------- */
 /* collision primitives (collision/sphere_*.hh), one lane                     */
 /* ------------------------------------------------------------------------- */
 
@@ -760,6 +1038,10 @@ static int sphere_environment_in_collision(const vo_env *e, const float *sx, con
     for (int l = 0; l < lanes; ++l) radii[l] = sr;
     for (size_t i = 0; i < e->n_capts; ++i)
         if (capt_collides_simd(&e->capts[i], sx, sy, sz, radii, lanes)) return 1;
+    /* validity.hh:149-155 */
+    for (size_t i = 0; i < e->n_mvts; ++i)
+        for (int l = 0; l < lanes; ++l)
+            if (mvt_collides_lane(&e->mvts[i], sx[l], sy[l], sz[l], sr)) return 1;
     return 0;
 }
 

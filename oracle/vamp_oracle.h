@@ -47,6 +47,25 @@ void vo_env_add_capsule(vo_env *e, const float *p8);
 /* collision/capt.hh:296-369; returns 0 on success */
 int vo_env_add_capt(vo_env *e, const float *points_xyz, size_t n, float r_min, float r_max, float r_point);
 
+/* collision/mvt.hh:147-170 (Multi-level Voxel Table).  Returns 0 on success; a positive code names the condition under
+ * which the reference throws inside its noexcept constructor (std::terminate): 1 voxel capacity exceeded,
+ * 2 point coordinate pool exhausted, 3 voxel index (z-table) pool exhausted, 4 degenerate grid. */
+int vo_env_add_mvt(vo_env *e, const float *points_xyz, size_t n, float r_min, float r_max, const float *ws_min3,
+                   const float *ws_max3, float r_point);
+/* MVT::collides (scalar, mvt.hh:204-279) and collides_simd (mvt.hh:282-403) */
+int vo_mvt_collides(const vo_env *e, size_t index, const float c[3], float r);
+int vo_mvt_collides_simd(const vo_env *e, size_t index, const float *cx, const float *cy, const float *cz,
+                         const float *r, int lanes);
+typedef struct vo_mvt_view
+{
+    uint32_t grid_width, capacity, n_voxels, n_y_tables, n_z_tables;
+    float inverse_scale_factor;
+    float global_min[3], global_max[3];
+    const uint32_t *x_table, *y_tables, *z_tables, *voxel_count;
+    const float *voxel_bbox, *px, *py, *pz;
+} vo_mvt_view;
+int vo_env_mvt_view(const vo_env *e, size_t index, vo_mvt_view *out);
+
 /* counts after sorting/splitting: spheres, capsules, z_capsules, cuboids, z_cuboids, capts */
 void vo_env_counts(const vo_env *e, size_t counts[6]);
 /* copy the sorted primitive tables (for cross-checking the device upload) */

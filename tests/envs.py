@@ -12,8 +12,8 @@ import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from oracle_lib import SPHERE_CAGE  # noqa: E402
 
-from vamp_mvt_amd.workloads import (POINT_RADIUS, RADII, capsule, environment_from_spec, rot_cuboid,  # noqa: F401
-                                    shell_cloud, shell_spec, yaw_cuboid)
+from vamp_mvt_amd.workloads import (POINT_RADIUS, RADII, WORKSPACE, capsule, environment_from_spec,  # noqa: F401
+                                    rot_cuboid, shell_cloud, shell_spec, yaw_cuboid)
 
 
 def spec_for(kind, robot="panda", seed=0):
@@ -46,6 +46,21 @@ def spec_for(kind, robot="panda", seed=0):
         spec = shell_spec(seed + 5, 4, 4)
         spec.append(("capt", (shell_cloud(2000, seed + 7), r_min, r_max, POINT_RADIUS)))
         return spec
+    if kind == "mvt":  # the fork's Multi-level Voxel Table + a few primitives
+        r_min, r_max = RADII[robot]
+        lo, hi = WORKSPACE[robot]
+        # the reference sizes the table's pools for at most 10 % occupied voxels / 50 % occupied columns, so the
+        # coarse grids of the large-radius robots only take small clouds (larger ones abort there)
+        if robot in ("panda", "ur5"):
+            pts = shell_cloud(1500, seed + 9, 0.5, 1.0, 0.0, 1.2)
+        elif robot == "fetch":
+            pts = shell_cloud(200, seed + 9, 0.6, 0.8, 0.4, 0.9)
+        else:
+            pts = shell_cloud(60, seed + 9, 0.9, 1.0, 0.3, 0.6)
+            pts = pts[pts[:, 0] > 0.5]
+        spec = shell_spec(seed + 5, 3, 3)
+        spec.append(("mvt", (pts, r_min, r_max, lo, hi, POINT_RADIUS)))
+        return spec
     raise KeyError(kind)
 
 
@@ -58,6 +73,10 @@ def build_oracle_env(o, spec):
             e.add_cuboid(p)
         elif kind == "capsule":
             e.add_capsule(p)
+        elif kind == "mvt":
+            rc = e.add_mvt(*p)
+            if rc != 0:
+                raise ValueError(f"oracle MVT build failed with reason {rc}")
         else:
             e.add_capt(*p)
     return e

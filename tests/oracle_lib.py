@@ -22,6 +22,16 @@ def _f(a):
     return a.ctypes.data_as(_fp)
 
 
+class MvtView(ctypes.Structure):
+    _fields_ = [("grid_width", ctypes.c_uint32), ("capacity", ctypes.c_uint32), ("n_voxels", ctypes.c_uint32),
+                ("n_y_tables", ctypes.c_uint32), ("n_z_tables", ctypes.c_uint32),
+                ("inverse_scale_factor", ctypes.c_float), ("global_min", ctypes.c_float * 3),
+                ("global_max", ctypes.c_float * 3), ("x_table", ctypes.POINTER(ctypes.c_uint32)),
+                ("y_tables", ctypes.POINTER(ctypes.c_uint32)), ("z_tables", ctypes.POINTER(ctypes.c_uint32)),
+                ("voxel_count", ctypes.POINTER(ctypes.c_uint32)), ("voxel_bbox", _fp), ("px", _fp), ("py", _fp),
+                ("pz", _fp)]
+
+
 class CaptView(ctypes.Structure):
     _fields_ = [("nlog2", ctypes.c_uint32), ("n_tests", ctypes.c_uint32), ("n_leaves", ctypes.c_uint32),
                 ("n_aff_vectors", ctypes.c_uint32), ("tests", _fp), ("aff_starts", ctypes.POINTER(ctypes.c_uint32)),
@@ -53,6 +63,12 @@ class Oracle:
         L.vo_env_add_capsule.argtypes = [ctypes.c_void_p, _fp]
         L.vo_env_add_capt.argtypes = [ctypes.c_void_p, _fp, ctypes.c_size_t] + [ctypes.c_float] * 3
         L.vo_env_add_capt.restype = ctypes.c_int
+        L.vo_env_add_mvt.argtypes = [ctypes.c_void_p, _fp, ctypes.c_size_t, ctypes.c_float, ctypes.c_float, _fp, _fp,
+                                     ctypes.c_float]
+        L.vo_env_add_mvt.restype = ctypes.c_int
+        L.vo_mvt_collides.argtypes = [ctypes.c_void_p, ctypes.c_size_t, _fp, ctypes.c_float]
+        L.vo_mvt_collides_simd.argtypes = [ctypes.c_void_p, ctypes.c_size_t, _fp, _fp, _fp, _fp, ctypes.c_int]
+        L.vo_env_mvt_view.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(MvtView)]
         L.vo_env_counts.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_size_t)]
         for fn in ("vo_env_get_spheres",):
             getattr(L, fn).argtypes = [ctypes.c_void_p, _fp]
@@ -193,6 +209,29 @@ class OracleEnv:
         rc = self.o.L.vo_env_add_capt(self.h, _f(p), p.shape[0], float(r_min), float(r_max), float(r_point))
         if rc != 0:
             raise ValueError("capt build failed")
+
+    def add_mvt(self, points, r_min, r_max, ws_min, ws_max, r_point):
+        """-> 0 ok, else the reason code under which the reference would throw"""
+        p = np.ascontiguousarray(points, np.float32)
+        lo, hi = np.ascontiguousarray(ws_min, np.float32), np.ascontiguousarray(ws_max, np.float32)
+        return int(self.o.L.vo_env_add_mvt(self.h, _f(p), p.shape[0], float(r_min), float(r_max), _f(lo), _f(hi),
+                                           float(r_point)))
+
+    def mvt(self, index=0):
+        v = MvtView()
+        if self.o.L.vo_env_mvt_view(self.h, index, ctypes.byref(v)) != 0:
+            raise IndexError(index)
+        return dict(grid_width=v.grid_width, capacity=v.capacity, n_voxels=v.n_voxels, n_z_tables=v.n_z_tables,
+                    inverse_scale_factor=v.inverse_scale_factor,
+                    global_box=np.array(list(v.global_min) + list(v.global_max), np.float32))
+
+    def mvt_collides(self, c, r, index=0):
+        c = np.ascontiguousarray(c, np.float32)
+        return bool(self.o.L.vo_mvt_collides(self.h, index, _f(c), float(r)))
+
+    def mvt_collides_simd(self, cx, cy, cz, r, index=0):
+        cx, cy, cz, r = (np.ascontiguousarray(a, np.float32) for a in (cx, cy, cz, r))
+        return bool(self.o.L.vo_mvt_collides_simd(self.h, index, _f(cx), _f(cy), _f(cz), _f(r), cx.size))
 
     def counts(self):
         c = (ctypes.c_size_t * 6)()

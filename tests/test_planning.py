@@ -53,3 +53,14 @@ def test_batched_roadmap_edges_match_oracle(vamp, oracle):
     if path is not None:
         for a, b in zip(path[:-1], path[1:]):
             assert oracle.validate_motion(rid, oenv, rm.vertices[a], rm.vertices[b])
+
+
+@pytest.mark.gpu
+def test_device_halton_bit_exact_vs_reference(vamp, golden_dir):
+    pytest.importorskip("torch")
+    vamp.set_device(0)
+    want = np.load(os.path.join(golden_dir, "halton_panda.npz"))["samples"]
+    got = vamp.panda.halton_device(20001).cpu().numpy()
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    part = vamp.panda.halton_device(100, skip=12345).cpu().numpy()
+    assert np.array_equal(part.view(np.uint32), want[12345:12445].view(np.uint32))

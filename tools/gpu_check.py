@@ -28,9 +28,9 @@ def main():
         mod = getattr(vamp, name)
         rid = o.robot(name)
         lo, span = o.bounds(rid)
-        for kind in ("empty", "cage", "shell64", "mixed", "capt"):
+        for kind in ("empty", "cage", "shell64", "mixed", "capt", "mvt"):
             env, oenv = make_env(kind, o, name)
-            n = 4096 if kind != "capt" else 2048
+            n = 4096 if kind not in ("capt", "mvt") else 2048
             q = (lo + span * rng.random((n, len(lo)), dtype=np.float32)).astype(np.float32)
             t = time.time()
             got = mod.validate_batch(q, env)
@@ -39,7 +39,7 @@ def main():
             want = o.validate_batch(rid, oenv, q, threads=8)
             tc = time.time() - t
             bad = int((got != want).sum())
-            ne = 512 if kind != "capt" else 256
+            ne = 512 if kind not in ("capt", "mvt") else 256
             a = q[:ne]
             b = (a + rng.normal(0, 0.3, a.shape).astype(np.float32)).astype(np.float32)
             got_e = mod.validate_motion_batch(a, b, env)

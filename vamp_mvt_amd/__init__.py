@@ -204,6 +204,25 @@ class Environment:
             lib.vmv_env_destroy(h)
         return int(ns.value)
 
+    def add_mvt_pointcloud(self, points, r_min, r_max, workspace_aabb_min, workspace_aabb_max, r_point):
+        """-> MVT build time in nanoseconds (environment.cc:164-177).  Raises VmvError(VMV_ERR_CAPACITY) where the
+        reference would terminate on an exhausted pool (mvt.hh:634-648)."""
+        pts = _f32(points)
+        if pts.ndim != 2 or pts.shape[1] != 3:
+            raise TypeError("points must be [n][3]")
+        lo, hi = _f32(workspace_aabb_min, (3,)), _f32(workspace_aabb_max, (3,))
+        h = ctypes.c_void_p()
+        check(lib.vmv_env_create(ctypes.byref(h)), "vmv_env_create")
+        ns = ctypes.c_uint64(0)
+        try:
+            check(lib.vmv_env_add_mvt_pointcloud(h, _fp(pts), pts.shape[0], r_min, r_max, _fp(lo), _fp(hi), r_point,
+                                                 ctypes.byref(ns), None), "vmv_env_add_mvt_pointcloud")
+        finally:
+            lib.vmv_env_destroy(h)
+        self._ops.append(("mvt", (pts.copy(), float(r_min), float(r_max), lo.copy(), hi.copy(), float(r_point))))
+        self._dirty()
+        return int(ns.value)
+
     def __del__(self):
         try:
             self._dirty()
@@ -222,6 +241,10 @@ class Environment:
                     check(lib.vmv_env_add_cuboid(h, _fp(arg)), "vmv_env_add_cuboid")
                 elif kind == "capsule":
                     check(lib.vmv_env_add_capsule(h, _fp(arg)), "vmv_env_add_capsule")
+                elif kind == "mvt":
+                    pts, r_min, r_max, lo, hi, r_point = arg
+                    check(lib.vmv_env_add_mvt_pointcloud(h, _fp(pts), pts.shape[0], r_min, r_max, _fp(lo), _fp(hi),
+                                                         r_point, None, None), "vmv_env_add_mvt_pointcloud")
                 else:
                     pts, r_min, r_max, r_point = arg
                     check(lib.vmv_env_add_capt_pointcloud(h, _fp(pts), pts.shape[0], r_min, r_max, r_point, None),
@@ -391,6 +414,17 @@ class _Robot(types.ModuleType):
         out = np.zeros((q.shape[0], self._ns, 4), np.float32)
         check(lib.vmv_fk_batch_host(self._id, _fp(q), q.shape[0], _fp(out)), "vmv_fk_batch_host")
         return out
+
+    def halton_device(self, n: int, skip: int = 0):
+        """Samples skip+1 .. skip+n of the reference's Halton sequence (random/halton.hh), generated on the GPU.
+        Returns a torch float32 CUDA tensor [n][dimension] (bit-exact against the reference's sequence)."""
+        import torch
+
+        q = torch.empty((n, self._dim), dtype=torch.float32, device="cuda")
+        stream = ctypes.c_void_p(torch.cuda.current_stream(q.device).cuda_stream)
+        check(lib.vmv_halton_configs(self._id, int(skip), ctypes.c_void_p(q.data_ptr()), n, stream),
+              "vmv_halton_configs")
+        return q
 
     # device-resident (torch tensors are only the memory/stream plumbing) ------------------------------------
     def validate_bits_device(self, q, environment, bits, goals=None):

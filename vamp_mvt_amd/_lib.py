@@ -76,6 +76,9 @@ def _load():
         "vmv_env_add_cuboid": (I, [V, c_float_p]),
         "vmv_env_add_capsule": (I, [V, c_float_p]),
         "vmv_env_add_capt_pointcloud": (I, [V, c_float_p, S, F, F, F, c_u64_p]),
+        "vmv_env_add_mvt_pointcloud": (I, [V, c_float_p, S, F, F, c_float_p, c_float_p, F, c_u64_p, ctypes.POINTER(I)]),
+        "vmv_env_mvt_count": (I, [V, c_size_p]),
+        "vmv_env_mvt_info": (I, [V, S, c_u32_p, c_u32_p, c_u32_p, c_float_p, c_float_p]),
         "vmv_env_finalize": (I, [V]),
         "vmv_env_counts": (I, [V, c_size_p]),
         "vmv_env_get_spheres": (I, [V, c_float_p, S, c_size_p]),
@@ -91,6 +94,7 @@ def _load():
         "vmv_fk_batch_host": (I, [I, c_float_p, S, c_float_p]),
         "vmv_validate_batch_host": (I, [I, V, c_float_p, S, c_u64_p]),
         "vmv_validate_motion_batch_host": (I, [I, V, c_float_p, c_float_p, S, c_u64_p]),
+        "vmv_halton_configs": (I, [I, ctypes.c_uint64, V, S, V]),
         "vmv_time_validate_batch": (I, [I, V, V, S, V, I, V, c_float_p]),
         "vmv_fill_uniform_configs": (I, [I, V, S, ctypes.c_uint64, V]),
         "vmv_kernel_name": (ctypes.c_char_p, [I, ctypes.c_char_p]),

@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "vmv_capt_build.h"
+#include "vmv_mvt_build.h"
 #include "vmv_common.h"
 
 // ---------------------------------------------------------------------------------------------------------
@@ -85,6 +86,28 @@ namespace vmv
         const int j = (int) (i % (size_t) dim);
         q[i] = lower[j] + span[j] * u;
     }
+
+    // Halton sample (skip + 1 + row) of the reference's sequence, element j (random/halton.hh:75-108): the
+    // incremental float arithmetic there keeps exact integers n, d = b^k, so the value is n / d with n the
+    // digit-reversed index; then Robot::scale_configuration (q * s_m + s_a, two roundings).
+    __global__ void halton_kernel(float *q, size_t total, int dim, uint64_t skip, const float *lower, const float *span)
+    {
+        const size_t idx = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+        if (idx >= total) return;
+        const uint32_t primes[16] = {3, 5, 7, 11, 13, 17, 19, 23, 29, 31, 37, 41, 43, 47, 53, 59};
+        const int j = (int) (idx % (size_t) dim);
+        uint64_t k = skip + idx / (size_t) dim + 1;
+        const uint32_t b = primes[j];
+        uint32_t n = 0, d = 1;
+        while (k > 0)
+        {
+            n = n * b + (uint32_t) (k % b);
+            d *= b;
+            k /= b;
+        }
+        const float u = (float) n / (float) d;
+        q[idx] = u * span[j] + lower[j];
+    }
 }  // namespace vmv
 
 // ---------------------------------------------------------------------------------------------------------
@@ -110,6 +133,7 @@ struct vmv_env
     std::vector<Capsule> capsules, z_capsules;
     std::vector<Cuboid> cuboids, z_cuboids;
     std::vector<vmv::CaptArrays> capts;
+    std::vector<vmv::MvtArrays> mvts;
 
     bool finalized = false;
     int device = -1;
@@ -315,6 +339,53 @@ extern "C"
         return VMV_OK;
     }
 
+    int vmv_env_add_mvt_pointcloud(vmv_env *env, const float *pts, size_t n, float r_min, float r_max,
+                                   const float *ws_min, const float *ws_max, float r_point, uint64_t *build_ns,
+                                   int *reason)
+    {
+        VMV_MUTABLE(env)
+        if (reason) *reason = 0;
+        if (!pts || !ws_min || !ws_max) return VMV_ERR_INVALID_ARGUMENT;
+        if (env->mvts.size() >= (size_t) vmv::kMaxMvt) return VMV_ERR_CAPACITY;
+        const auto t0 = std::chrono::steady_clock::now();
+        vmv::MvtArrays arrays;
+        const vmv::MvtStatus st = vmv::build_mvt(pts, n, r_min, r_max, ws_min, ws_max, r_point, arrays);
+        if (st != vmv::MvtStatus::ok)
+        {
+            if (reason) *reason = (int) st;
+            g_last_error = "MVT: a pool the reference sizes up front would be exhausted (see vmv_mvt_build.h)";
+            return VMV_ERR_CAPACITY;
+        }
+        env->mvts.push_back(std::move(arrays));
+        if (build_ns)
+            *build_ns = (uint64_t) std::chrono::duration_cast<std::chrono::nanoseconds>(
+                            std::chrono::steady_clock::now() - t0)
+                            .count();
+        return VMV_OK;
+    }
+
+    int vmv_env_mvt_count(const vmv_env *env, size_t *count)
+    {
+        if (!env || !count) return VMV_ERR_INVALID_ARGUMENT;
+        *count = env->mvts.size();
+        return VMV_OK;
+    }
+    int vmv_env_mvt_info(const vmv_env *env, size_t index, uint32_t *gw, uint32_t *cap, uint32_t *nv, float *isf, float *box)
+    {
+        if (!env || index >= env->mvts.size()) return VMV_ERR_INVALID_ARGUMENT;
+        const vmv::MvtArrays &m = env->mvts[index];
+        if (gw) *gw = m.grid_width;
+        if (cap) *cap = m.capacity;
+        if (nv) *nv = m.n_voxels();
+        if (isf) *isf = m.inv_scale;
+        if (box)
+        {
+            std::memcpy(box, m.gmin, 12);
+            std::memcpy(box + 3, m.gmax, 12);
+        }
+        return VMV_OK;
+    }
+
     int vmv_env_finalize(vmv_env *env)
     {
         VMV_MUTABLE(env)
@@ -394,6 +465,24 @@ extern "C"
             c.n_tests = (uint32_t) a.tests.size();
         }
         D.capt0_n_tests = D.n_capt ? (uint32_t) env->capts[0].tests.size() : 0u;
+        D.n_mvt = (uint32_t) env->mvts.size();
+        for (size_t i = 0; i < env->mvts.size(); ++i)
+        {
+            const vmv::MvtArrays &m = env->mvts[i];
+            vmv::MvtDev &d = D.mvt[i];
+            if ((rc = upload(env, m.cells, &d.cells)) != VMV_OK) return rc;
+            if ((rc = upload(env, m.vox_bbox, &d.vox_bbox)) != VMV_OK) return rc;
+            if ((rc = upload(env, m.vox_offset, &d.vox_offset)) != VMV_OK) return rc;
+            if ((rc = upload(env, m.px, &d.px)) != VMV_OK) return rc;
+            if ((rc = upload(env, m.py, &d.py)) != VMV_OK) return rc;
+            if ((rc = upload(env, m.pz, &d.pz)) != VMV_OK) return rc;
+            std::memcpy(d.gmin, m.gmin, 12);
+            std::memcpy(d.gmax, m.gmax, 12);
+            std::memcpy(d.ws_min, m.ws_min, 12);
+            d.inv_scale = m.inv_scale;
+            d.r_point = m.r_point;
+            d.grid_width = m.grid_width;
+        }
         {
             std::vector<vmv::EnvDev> one(1, D);
             if ((rc = upload(env, one, &env->launch.d_env)) != VMV_OK) return rc;
@@ -607,6 +696,25 @@ extern "C"
         const size_t total = n * (size_t) dim;
         hipLaunchKernelGGL(vmv::fill_uniform_kernel, dim3((unsigned) ((total + 255) / 256)), dim3(256), 0,
                            static_cast<hipStream_t>(stream), d_q, total, dim, seed, d_bounds, d_bounds + 16);
+        VMV_HIP(hipGetLastError());
+        VMV_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+        (void) hipFree(d_bounds);
+        return VMV_OK;
+    }
+
+    int vmv_halton_configs(int robot, uint64_t skip, float *d_q, size_t n, void *stream)
+    {
+        if (!robot_ok(robot)) return VMV_ERR_UNKNOWN_ROBOT;
+        if (!d_q || skip + n > 1000000ull) return VMV_ERR_INVALID_ARGUMENT;
+        if (n == 0) return VMV_OK;
+        const int dim = kRobots[robot].dimension;
+        float *d_bounds = nullptr;
+        VMV_HIP(hipMalloc((void **) &d_bounds, 32 * sizeof(float)));
+        VMV_HIP(hipMemcpy(d_bounds, kRobots[robot].lower, 16 * sizeof(float), hipMemcpyHostToDevice));
+        VMV_HIP(hipMemcpy(d_bounds + 16, kRobots[robot].span, 16 * sizeof(float), hipMemcpyHostToDevice));
+        const size_t total = n * (size_t) dim;
+        hipLaunchKernelGGL(vmv::halton_kernel, dim3((unsigned) ((total + 255) / 256)), dim3(256), 0,
+                           static_cast<hipStream_t>(stream), d_q, total, dim, skip, d_bounds, d_bounds + 16);
         VMV_HIP(hipGetLastError());
         VMV_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
         (void) hipFree(d_bounds);

@@ -152,6 +152,20 @@ namespace vmv
 
     constexpr int kMaxCapt = 4;
 
+    // Multi-level Voxel Table (collision/mvt.hh) as the query reads it: one dense grid of voxel indices (the
+    // reference's three pointer levels collapsed; see vmv_mvt_build.h), voxel boxes, compact SoA points.
+    struct MvtDev
+    {
+        const uint32_t *cells;       // grid_width^3 -> voxel index or 0xffffffff
+        const float *vox_bbox;       // [n_vox][6]
+        const uint32_t *vox_offset;  // [n_vox + 1]
+        const float *px, *py, *pz;
+        float gmin[3], gmax[3], ws_min[3];
+        float inv_scale, r_point;
+        uint32_t grid_width;
+    };
+    constexpr int kMaxMvt = 4;
+
     struct EnvDev  // kernel argument (by value)
     {
         const float *prims;  // HBM image of the LDS primitive block
@@ -161,7 +175,9 @@ namespace vmv
         uint32_t off_md_sphere, off_md_capsule, off_md_zcapsule, off_md_cuboid, off_md_zcuboid;  // min_distance arrays
         uint32_t n_capt;
         uint32_t capt0_n_tests;  // size of capt[0].tests (candidate for LDS staging behind the primitive block)
+        uint32_t n_mvt;
         CaptDev capt[kMaxCapt];
+        MvtDev mvt[kMaxMvt];
     };
 
     // explicit address spaces for everything that crosses a non-inlined call: the constant space makes the
@@ -257,6 +273,81 @@ namespace vmv
                 h |= sql2_3(x1.w, y1.w, z1.w, x, y, z) <= rc_sq;
                 hit = h;
                 ++i;
+            }
+        }
+        return hit;
+    }
+
+    // MVT::collides (collision/mvt.hh:204-279) == one lane of collides_simd (mvt.hh:282-403; lanes are
+    // independent there, the 8-point chunks only add +inf padding that never collides).  Per lane: global box
+    // test, the <= 3 x 3 x 3 cells around the centre (grid_query_radius is clamped to one cell, which is what makes
+    // the answer structure-dependent for radii above r_max), voxel box cull, then the voxel's points with `<=`.
+    // Float -> uint16 casts apply to in-range values as written; where the reference's cast is undefined
+    // (negative upper bound, outside the global-box pre-test only for radii > 1 cell) the range is empty.
+    __device__ __forceinline__ bool
+    mvt_collides(env_cptr D, const uint32_t mi, float x, float y, float z, float r, bool active)
+    {
+        const float qr = r + D->mvt[mi].r_point;
+        const float qr2 = qr * qr;
+        bool in = active;
+        in = in && !(x + qr < D->mvt[mi].gmin[0] || x - qr > D->mvt[mi].gmax[0]);
+        in = in && !(y + qr < D->mvt[mi].gmin[1] || y - qr > D->mvt[mi].gmax[1]);
+        in = in && !(z + qr < D->mvt[mi].gmin[2] || z - qr > D->mvt[mi].gmax[2]);
+        if (!wave_any(in)) return false;
+
+        const float isf = D->mvt[mi].inv_scale;
+        const uint32_t gw = D->mvt[mi].grid_width;
+        const float top = (float) (gw - 1);
+        const float gqr = fminf(1.0f, qr * isf);
+        const float gx = (x - D->mvt[mi].ws_min[0]) * isf, gy = (y - D->mvt[mi].ws_min[1]) * isf,
+                    gz = (z - D->mvt[mi].ws_min[2]) * isf;
+        const float bx = fminf(top, gx + gqr), by = fminf(top, gy + gqr), bz = fminf(top, gz + gqr);
+        in = in && !(bx < 0.0f || by < 0.0f || bz < 0.0f);
+        const uint32_t x0 = (uint32_t) (uint16_t) fmaxf(0.0f, gx - gqr), y0 = (uint32_t) (uint16_t) fmaxf(0.0f, gy - gqr),
+                       z0 = (uint32_t) (uint16_t) fmaxf(0.0f, gz - gqr);
+        const uint32_t x1 = (uint32_t) (uint16_t) fmaxf(bx, 0.0f), y1 = (uint32_t) (uint16_t) fmaxf(by, 0.0f),
+                       z1 = (uint32_t) (uint16_t) fmaxf(bz, 0.0f);
+        // flattened walk over this lane's cell range (x outer, z inner, as the reference)
+        const uint32_t ny = (y1 >= y0) ? y1 - y0 + 1 : 0, nz = (z1 >= z0) ? z1 - z0 + 1 : 0;
+        const uint32_t nx = (x1 >= x0) ? x1 - x0 + 1 : 0;
+        const uint32_t n_cells = in ? nx * ny * nz : 0u;
+        const gu_cptr cells = (gu_cptr) D->mvt[mi].cells;
+        const gf_cptr boxes = (gf_cptr) D->mvt[mi].vox_bbox;
+        const gu_cptr offs = (gu_cptr) D->mvt[mi].vox_offset;
+        const gf_cptr px = (gf_cptr) D->mvt[mi].px, py = (gf_cptr) D->mvt[mi].py, pz = (gf_cptr) D->mvt[mi].pz;
+        bool hit = false;
+        for (uint32_t c = 0; wave_any(!hit && c < n_cells); ++c)
+        {
+            uint32_t i = 0, end = 0;
+            if (!hit && c < n_cells)
+            {
+                const uint32_t cz = c % nz, cy = (c / nz) % ny, cx = c / (nz * ny);
+                const uint32_t vi = cells[((size_t) (x0 + cx) * gw + (y0 + cy)) * gw + (z0 + cz)];
+                if (vi != 0xffffffffu)
+                {
+                    const gf_cptr bb = boxes + 6 * (size_t) vi;
+                    const bool cull = x + qr < bb[0] || x - qr > bb[3] || y + qr < bb[1] || y - qr > bb[4] ||
+                                      z + qr < bb[2] || z - qr > bb[5];
+                    if (!cull)
+                    {
+                        i = offs[vi];
+                        end = offs[vi + 1];
+                    }
+                }
+            }
+            while (wave_any(i < end))
+            {
+                if (i < end)
+                {
+                    const float dx = x - px[i], dy = y - py[i], dz = z - pz[i];
+                    if (dx * dx + dy * dy + dz * dz <= qr2)
+                    {
+                        hit = true;
+                        i = end;
+                    }
+                    else
+                        ++i;
+                }
             }
         }
         return hit;
@@ -445,6 +536,12 @@ namespace vmv
             const bool act = active && !hit;
             if (!wave_any(act)) break;
             hit |= capt_collides(Dp, ci, E.lds + D.n_floats, (ci == 0) ? E.capt0_planes_in_lds : 0u, x, y, z, r, act);
+        }
+        for (uint32_t mi = 0; mi < D.n_mvt; ++mi)  // validity.hh:149-155
+        {
+            const bool act = active && !hit;
+            if (!wave_any(act)) break;
+            hit |= mvt_collides(Dp, mi, x, y, z, r, act);
         }
         return hit;
 #undef D

@@ -59,6 +59,11 @@ SPHERE_CAGE = [  # problem data of the reference's scripts/sphere_cage_example.p
     [0, -0.55, 0.8], [0.35, -0.35, 0.8]]
 
 
+WORKSPACE = {  # workspace boxes as src/vamp/pointcloud.py builds them: first-joint location +- max reach
+    "panda": ([-1.19, -1.19, -0.857], [1.19, 1.19, 1.523]), "ur5": ([-1.2, -1.2, -0.29], [1.2, 1.2, 2.11]),
+    "fetch": ([-1.4, -1.4, -1.0], [1.5, 1.4, 1.8]), "baxter": ([-1.5, -1.5, -1.2], [1.5, 1.5, 1.8])}
+
+
 def environment_from_spec(spec):
     """spec: list of (kind, params) -> vamp_mvt_amd.Environment"""
     import vamp_mvt_amd as vamp
@@ -71,6 +76,8 @@ def environment_from_spec(spec):
             e.add_cuboid(vamp.Cuboid.from_canonical(p))
         elif kind == "capsule":
             e.add_capsule(vamp.Cylinder.from_canonical(p))
+        elif kind == "mvt":
+            e.add_mvt_pointcloud(*p)
         else:
             e.add_capt_pointcloud(*p)
     return e
