@@ -488,6 +488,12 @@ def trace(urdf, srdf, joint_names, end_effector=None, bounding=None, resolution=
                      for i in link_spheres[ln]]
             c, r = min_enclosing_ball(balls)
             r32 = np.float32(r)
+        # every fine sphere lies inside the bounding sphere (the kernels' candidate pruning relies on it with a 1e-4 m
+        # margin, vmv_device.h kCandidateMargin): enforce it here, in the link frame, to 2e-6 m
+        for i_f in link_spheres[ln]:
+            gap = np.linalg.norm(np.array(spheres[i_f]["local"], np.float64) - c) + float(np.float32(spheres[i_f]["rad"])) \
+                - float(r32)
+            assert gap <= 2e-6, (ln, i_f, gap)
         # the bounding centre is kept as fp32 in the frame of the link's movable joint
         p_joint = fr.act(c).astype(np.float32).astype(np.float64)
         p_joint[np.abs(p_joint) < 1e-12] = 0.0  # round-off of this solver / of the fixed-frame product is not geometry

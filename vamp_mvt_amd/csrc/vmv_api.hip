@@ -437,6 +437,20 @@ extern "C"
         md_array(env->z_capsules, D.off_md_zcapsule);
         md_array(env->cuboids, D.off_md_cuboid);
         md_array(env->z_cuboids, D.off_md_zcuboid);
+        {  // candidate words of the fine phase (vmv_device.h, kCandidateMargin): 32 primitives per word, per list
+            uint32_t w = 0;
+            auto words = [&](uint32_t n, uint32_t &base)
+            {
+                base = w;
+                w += (n + 31u) / 32u;
+            };
+            words(D.n_sphere, D.wbase_sphere);
+            words(D.n_capsule, D.wbase_capsule);
+            words(D.n_zcapsule, D.wbase_zcapsule);
+            words(D.n_cuboid, D.wbase_cuboid);
+            words(D.n_zcuboid, D.wbase_zcuboid);
+            D.masked_fine = (w <= (uint32_t) vmv::kMaskWords) ? 1u : 0u;
+        }
         while (block.size() % 4) block.push_back(0.f);
         if (block.size() > kMaxPrimFloats)
         {

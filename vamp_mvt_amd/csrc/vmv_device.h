@@ -173,6 +173,8 @@ namespace vmv
         uint32_t n_sphere, n_capsule, n_zcapsule, n_cuboid, n_zcuboid;
         uint32_t off_sphere, off_capsule, off_zcapsule, off_cuboid, off_zcuboid;  // float offsets in the block
         uint32_t off_md_sphere, off_md_capsule, off_md_zcapsule, off_md_cuboid, off_md_zcuboid;  // min_distance arrays
+        // candidate words (32 primitives each) per list: first word index, and whether all lists fit kMaskWords
+        uint32_t wbase_sphere, wbase_capsule, wbase_zcapsule, wbase_cuboid, wbase_zcuboid, masked_fine;
         uint32_t n_capt;
         uint32_t capt0_n_tests;  // size of capt[0].tests (candidate for LDS staging behind the primitive block)
         uint32_t n_mvt;
@@ -407,19 +409,12 @@ namespace vmv
         return count;
     }
 
-    // sphere_environment_in_collision (collision/validity.hh:47-158) for one robot sphere, per lane.
-    //  * returns this lane's own "hits something" flag; the caller folds it over the rake with group_any.
-    //  * the sorted early-break is rake-wide in the reference (all 8 lanes must agree).  Lists are sorted
-    //    by min_distance, so "all lanes have min_distance - max_extent >= 0" is the same predicate
-    //    evaluated on the rake's largest max_extent: ext = group_max(max_extent).
-    //  * max_extent uses the correctly rounded sqrt (the reference's v*rsqrt_ps(v) is vendor-defined).
-    //  * loops are counted: the trip count is the live prefix for the largest max_extent in the wave; each
-    //    lane still applies its own break predicate, so the per-lane answer is the reference's.
-    //  * `active` only prunes work: inactive lanes do not extend the trip counts and report no hit.
+    typedef __attribute__((address_space(3))) uint32_t lds_u32;
+
     // Where the wave-uniform primitive records are read from inside the counted loops.
     //   VMV_PRIMS_SCALAR = 1: straight from the environment block through the scalar cache (s_load_dwordx4 into
     //       SGPRs that the VALU consumes directly) - keeps the LDS pipe free for the per-lane traffic (sphere slab,
-    //       re-dealt items, min_distance prefix counts, CAPT split planes);
+    //       re-dealt items, min_distance prefix counts, candidate gathers, CAPT split planes);
     //   VMV_PRIMS_SCALAR = 0: from the LDS copy of the block (64-lane broadcast ds_read_b128).
 #ifndef VMV_PRIMS_SCALAR
 #define VMV_PRIMS_SCALAR 1
@@ -431,104 +426,222 @@ namespace vmv
 #define VMV_REC_BASE(E, D) ((rec_cptr) (D).prims)
 #else
     using rec_cptr = lds_cptr;
-    __device__ __forceinline__ v4f rec_load4(rec_cptr p) { return lds_load4(p); }
 #define VMV_REC_BASE(E, D) ((E).lds)
 #endif
 
-    template <int G>
-    __device__ __forceinline__ bool env_hit(const EnvView &E, float x, float y, float z, float r, bool active)
+    // ------------------------------------------------------------------------
+    // one primitive against one sphere: the reference's signed test value (collision iff its sign bit is set),
+    // the primitive's min_distance, and the length the candidate margin scales with.
+    // ------------------------------------------------------------------------
+    enum PrimType
+    {
+        kSphere = 0,
+        kCapsule = 1,
+        kZCapsule = 2,
+        kCuboid = 3,
+        kZCuboid = 4
+    };
+    template <int T>
+    struct PrimTraits;
+    template <> struct PrimTraits<kSphere> { static constexpr int rec = kSphereRec; };
+    template <> struct PrimTraits<kCapsule> { static constexpr int rec = kCapsuleRec; };
+    template <> struct PrimTraits<kZCapsule> { static constexpr int rec = kZCapsuleRec; };
+    template <> struct PrimTraits<kCuboid> { static constexpr int rec = kCuboidRec; };
+    template <> struct PrimTraits<kZCuboid> { static constexpr int rec = kZCuboidRec; };
+
+    __device__ __forceinline__ v4f load4(lds_cptr p) { return lds_load4(p); }
+#if VMV_PRIMS_SCALAR
+    __device__ __forceinline__ v4f load4(rec_cptr p) { return rec_load4(p); }
+#endif
+
+    template <int T, typename PTR>
+    __device__ __forceinline__ void
+    prim_eval(PTR rec, float x, float y, float z, float r, float rsq, float &v, float &md, float &reach)
+    {
+        if constexpr (T == kSphere)
+        {
+            const v4f a = load4(rec);  // x y z r | min_d
+            md = rec[4];
+            reach = a.w + r;  // collision/sphere_sphere.hh:9-23: rs = ar + br
+            v = sql2_3(a.x, a.y, a.z, x, y, z) - reach * reach;
+        }
+        else if constexpr (T == kCapsule)
+        {
+            const v4f a = load4(rec);      // x1 y1 z1 xv
+            const v4f b = load4(rec + 4);  // yv zv r rdv
+            md = rec[8];
+            // collision/sphere_capsule.hh:8-23
+            const float dot = dot3(x - a.x, y - a.y, z - a.z, a.w, b.x, b.y);
+            const float cdf = vclamp(dot * b.w, 0.F, 1.F);
+            const float sum = sql2_3(x, y, z, a.x + a.w * cdf, a.y + b.x * cdf, a.z + b.y * cdf);
+            reach = r + b.z;
+            v = sum - reach * reach;
+        }
+        else if constexpr (T == kZCapsule)
+        {
+            const v4f a = load4(rec);      // x1 y1 z1 zv
+            const v4f b = load4(rec + 4);  // r rdv min_d 0
+            md = b.z;
+            // collision/sphere_capsule.hh:31-45
+            const float dot = (z - a.z) * a.w;
+            const float cdf = vclamp(dot * b.y, 0.F, 1.F);
+            const float sum = sql2_3(x, y, z, a.x, a.y, a.z + a.w * cdf);
+            reach = r + b.x;
+            v = sum - reach * reach;
+        }
+        else if constexpr (T == kCuboid)
+        {
+            const v4f a = load4(rec);       // x y z a1x
+            const v4f b = load4(rec + 4);   // a1y a1z a2x a2y
+            const v4f c = load4(rec + 8);   // a2z a3x a3y a3z
+            const v4f d = load4(rec + 12);  // r1 r2 r3 min_d
+            md = d.w;
+            // collision/sphere_cuboid.hh:8-27
+            const float xs = x - a.x, ys = y - a.y, zs = z - a.z;
+            const float a1 = x86_max(vabs(dot3(a.w, b.x, b.y, xs, ys, zs)) - d.x, 0.f);
+            const float a2 = x86_max(vabs(dot3(b.z, b.w, c.x, xs, ys, zs)) - d.y, 0.f);
+            const float a3 = x86_max(vabs(dot3(c.y, c.z, c.w, xs, ys, zs)) - d.z, 0.f);
+            reach = r;
+            v = dot3(a1, a2, a3, a1, a2, a3) - rsq;
+        }
+        else
+        {
+            const v4f a = load4(rec);      // x y z a1x
+            const v4f b = load4(rec + 4);  // a1y a2x a2y r1
+            const v4f c = load4(rec + 8);  // r2 r3 min_d 0
+            md = c.z;
+            // collision/sphere_cuboid.hh:35-52
+            const float xs = x - a.x, ys = y - a.y, zs = z - a.z;
+            const float a1 = x86_max(vabs((a.w * xs) + (b.x * ys)) - b.w, 0.f);
+            const float a2 = x86_max(vabs((b.y * xs) + (b.z * ys)) - c.x, 0.f);
+            const float a3 = x86_max(vabs(zs) - c.y, 0.f);
+            reach = r;
+            v = dot3(a1, a2, a3, a1, a2, a3) - rsq;
+        }
+    }
+
+    // Candidate margin.  A fine sphere lies inside its link's bounding sphere (the bounding sphere is the smallest
+    // ball enclosing the link's spheres; tools/robot_trace.py asserts the enclosure in the link frame, and rigid fp32
+    // FK preserves it to ~1e-6 m).  Every primitive test is `distance(centre, primitive)^2 - reach^2` with a
+    // 1-Lipschitz distance, so a primitive a fine sphere can collide with satisfies, for the bounding sphere,
+    // distance < reach_bounding + 1e-6.  The gate therefore records as candidates all primitives with
+    // distance < reach + kCandidateMargin (v < 2 * margin * reach + margin^2), two orders of magnitude wider than any
+    // fp32 error in FK or in the tests, and the fine spheres evaluate the reference's exact predicates on candidates
+    // only.  This prunes work; it cannot change an answer.
+    constexpr float kCandidateMargin = 1e-4f;
+    constexpr int kMaskWords = 4;  // 32-primitive candidate words per lane kept in LDS (environments with more use full loops)
+
+    // One sorted list, full counted loop over the live prefix (records through the scalar cache).  MASK: also
+    // write this lane's candidate words for the list to mask_lane[(word) * 64].
+    template <int G, int T, bool MASK>
+    __device__ __forceinline__ void list_full(const EnvView &E, const uint32_t n, const uint32_t off, const uint32_t off_md,
+                                              const uint32_t wbase, float x, float y, float z, float r, float rsq,
+                                              float ext, float ext_wave, bool &hit, lds_u32 *mask_lane)
+    {
+        if (n == 0) return;
+        constexpr int REC = PrimTraits<T>::rec;
+        const env_cptr Dp = E.dev;
+        // candidates need the loop to cover what any FINE sphere of the link may still test: a hair beyond the wave's
+        // largest bounding max_extent (fine max_extent <= bounding max_extent + ~1e-6)
+        const uint32_t n_live = live_prefix(E.lds + off_md, n, MASK ? ext_wave + 1e-3f : ext_wave);
+        rec_cptr rec = VMV_REC_BASE(E, (*Dp)) + off;
+        if constexpr (!MASK)
+        {
+#pragma unroll 2
+            for (uint32_t i = 0; i < n_live; ++i, rec += REC)
+            {
+                float v, md, reach;
+                prim_eval<T>(rec, x, y, z, r, rsq, v, md, reach);
+                hit |= neg(md - ext) && neg(v);
+            }
+        }
+        else
+        {
+            for (uint32_t b = 0; b < n_live; b += 32)
+            {
+                uint32_t m = 0;
+                const uint32_t e = (b + 32 < n_live) ? b + 32 : n_live;
+                for (uint32_t i = b; i < e; ++i, rec += REC)
+                {
+                    float v, md, reach;
+                    prim_eval<T>(rec, x, y, z, r, rsq, v, md, reach);
+                    hit |= neg(md - ext) && neg(v);
+                    const float tau = reach * (2.0f * kCandidateMargin) + kCandidateMargin * kCandidateMargin;
+                    m |= (v < tau) ? (1u << (i - b)) : 0u;
+                }
+                mask_lane[(wbase + (b >> 5)) * kWave] = m;
+            }
+        }
+    }
+
+    // One sorted list, candidates only: mask_src points at the candidate words of the lane this item works for.
+    template <int T>
+    __device__ __forceinline__ void list_masked(const EnvView &E, const uint32_t n, const uint32_t off, const uint32_t wbase,
+                                                float x, float y, float z, float r, float rsq, float ext, bool active,
+                                                bool &hit, const lds_u32 *mask_src)
+    {
+        if (n == 0) return;
+        constexpr int REC = PrimTraits<T>::rec;
+        const uint32_t words = (n + 31) / 32;
+        for (uint32_t w = 0; w < words; ++w)
+        {
+            uint32_t m = active ? mask_src[(wbase + w) * kWave] : 0u;
+            while (wave_any(m != 0u))
+            {
+                if (m != 0u)
+                {
+                    const uint32_t bit = (uint32_t) __ffs((int) m) - 1u;
+                    m &= m - 1u;
+                    lds_cptr rec = E.lds + off + (w * 32u + bit) * REC;  // per-lane record: LDS gather
+                    float v, md, reach;
+                    prim_eval<T>(rec, x, y, z, r, rsq, v, md, reach);
+                    hit |= neg(md - ext) && neg(v);
+                }
+            }
+        }
+    }
+
+    // sphere_environment_in_collision (collision/validity.hh:47-158) for one robot sphere, per lane.
+    //  * returns this lane's own "hits something" flag; the caller folds it over the rake with group_any.
+    //  * the sorted early-break is rake-wide in the reference (all 8 lanes must agree).  Lists are sorted
+    //    by min_distance, so "all lanes have min_distance - max_extent >= 0" is the same predicate
+    //    evaluated on the rake's largest max_extent: ext = group_max(max_extent).
+    //  * max_extent uses the correctly rounded sqrt (the reference's v*rsqrt_ps(v) is vendor-defined).
+    //  * MODE 0 (plain) / 1 (gate: also record candidate words): counted loops over the live prefix for the
+    //    largest max_extent in the wave; each lane still applies its own break predicate.
+    //    MODE 2 (fine): only the candidates the lane's bounding sphere recorded (see kCandidateMargin).
+    //  * `active` only prunes work: inactive lanes do not extend the trip counts and report no hit.
+    template <int G, int MODE>
+    __device__ __forceinline__ bool
+    env_hit(const EnvView &E, float x, float y, float z, float r, bool active, lds_u32 *mask)
     {
         const env_cptr Dp = E.dev;
 #define D (*Dp)
         const float ext = group_max<G>(sqrtf(dot3(x, y, z, x, y, z)) + r);
-        const float ext_wave = wave_max_nonneg(active ? ext : 0.0f);
-        bool hit = false;
-
-        if (D.n_sphere)
-        {
-            rec_cptr rec = VMV_REC_BASE(E, D) + D.off_sphere;
-            const uint32_t n = live_prefix(E.lds + D.off_md_sphere, D.n_sphere, ext_wave);
-#pragma unroll 2
-            for (uint32_t i = 0; i < n; ++i, rec += kSphereRec)
-            {
-                const v4f a = rec_load4(rec);
-                const bool live = neg(rec[4] - ext);
-                const bool h = neg(sphere_sphere_sql2(a.x, a.y, a.z, a.w, x, y, z, r));
-                hit |= (live && h);
-            }
-        }
-        if (D.n_capsule)
-        {
-            rec_cptr rec = VMV_REC_BASE(E, D) + D.off_capsule;
-            const uint32_t n = live_prefix(E.lds + D.off_md_capsule, D.n_capsule, ext_wave);
-            for (uint32_t i = 0; i < n; ++i, rec += kCapsuleRec)
-            {
-                const v4f a = rec_load4(rec);
-                const v4f b = rec_load4(rec + 4);
-                const bool live = neg(rec[8] - ext);
-                // collision/sphere_capsule.hh:8-23 (a = x1 y1 z1 xv, b = yv zv r rdv)
-                const float dot = dot3(x - a.x, y - a.y, z - a.z, a.w, b.x, b.y);
-                const float cdf = vclamp(dot * b.w, 0.F, 1.F);
-                const float sum = sql2_3(x, y, z, a.x + a.w * cdf, a.y + b.x * cdf, a.z + b.y * cdf);
-                const float rs = r + b.z;
-                hit |= (live && neg(sum - rs * rs));
-            }
-        }
-        if (D.n_zcapsule)
-        {
-            rec_cptr rec = VMV_REC_BASE(E, D) + D.off_zcapsule;
-            const uint32_t n = live_prefix(E.lds + D.off_md_zcapsule, D.n_zcapsule, ext_wave);
-            for (uint32_t i = 0; i < n; ++i, rec += kZCapsuleRec)
-            {
-                const v4f a = rec_load4(rec);      // x1 y1 z1 zv
-                const v4f b = rec_load4(rec + 4);  // r rdv min_d 0
-                const bool live = neg(b.z - ext);
-                // collision/sphere_capsule.hh:31-45
-                const float dot = (z - a.z) * a.w;
-                const float cdf = vclamp(dot * b.y, 0.F, 1.F);
-                const float sum = sql2_3(x, y, z, a.x, a.y, a.z + a.w * cdf);
-                const float rs = r + b.x;
-                hit |= (live && neg(sum - rs * rs));
-            }
-        }
         const float rsq = r * r;
-        if (D.n_cuboid)
+        bool hit = false;
+        if constexpr (MODE == 2)
         {
-            rec_cptr rec = VMV_REC_BASE(E, D) + D.off_cuboid;
-            const uint32_t n = live_prefix(E.lds + D.off_md_cuboid, D.n_cuboid, ext_wave);
-            for (uint32_t i = 0; i < n; ++i, rec += kCuboidRec)
-            {
-                const v4f a = rec_load4(rec);       // x y z a1x
-                const v4f b = rec_load4(rec + 4);   // a1y a1z a2x a2y
-                const v4f c = rec_load4(rec + 8);   // a2z a3x a3y a3z
-                const v4f d = rec_load4(rec + 12);  // r1 r2 r3 min_d
-                const bool live = neg(d.w - ext);
-                // collision/sphere_cuboid.hh:8-27
-                const float xs = x - a.x, ys = y - a.y, zs = z - a.z;
-                const float a1 = x86_max(vabs(dot3(a.w, b.x, b.y, xs, ys, zs)) - d.x, 0.f);
-                const float a2 = x86_max(vabs(dot3(b.z, b.w, c.x, xs, ys, zs)) - d.y, 0.f);
-                const float a3 = x86_max(vabs(dot3(c.y, c.z, c.w, xs, ys, zs)) - d.z, 0.f);
-                hit |= (live && neg(dot3(a1, a2, a3, a1, a2, a3) - rsq));
-            }
+            list_masked<kSphere>(E, D.n_sphere, D.off_sphere, D.wbase_sphere, x, y, z, r, rsq, ext, active, hit, mask);
+            list_masked<kCapsule>(E, D.n_capsule, D.off_capsule, D.wbase_capsule, x, y, z, r, rsq, ext, active, hit, mask);
+            list_masked<kZCapsule>(E, D.n_zcapsule, D.off_zcapsule, D.wbase_zcapsule, x, y, z, r, rsq, ext, active, hit, mask);
+            list_masked<kCuboid>(E, D.n_cuboid, D.off_cuboid, D.wbase_cuboid, x, y, z, r, rsq, ext, active, hit, mask);
+            list_masked<kZCuboid>(E, D.n_zcuboid, D.off_zcuboid, D.wbase_zcuboid, x, y, z, r, rsq, ext, active, hit, mask);
         }
-        if (D.n_zcuboid)
+        else
         {
-            rec_cptr rec = VMV_REC_BASE(E, D) + D.off_zcuboid;
-            const uint32_t n = live_prefix(E.lds + D.off_md_zcuboid, D.n_zcuboid, ext_wave);
-#pragma unroll 2
-            for (uint32_t i = 0; i < n; ++i, rec += kZCuboidRec)
-            {
-                const v4f a = rec_load4(rec);      // x y z a1x
-                const v4f b = rec_load4(rec + 4);  // a1y a2x a2y r1
-                const v4f c = rec_load4(rec + 8);  // r2 r3 min_d 0
-                const bool live = neg(c.z - ext);
-                // collision/sphere_cuboid.hh:35-52
-                const float xs = x - a.x, ys = y - a.y, zs = z - a.z;
-                const float a1 = x86_max(vabs((a.w * xs) + (b.x * ys)) - b.w, 0.f);
-                const float a2 = x86_max(vabs((b.y * xs) + (b.z * ys)) - c.x, 0.f);
-                const float a3 = x86_max(vabs(zs) - c.y, 0.f);
-                hit |= (live && neg(dot3(a1, a2, a3, a1, a2, a3) - rsq));
-            }
+            constexpr bool MASK = (MODE == 1);
+            const float ext_wave = wave_max_nonneg(active ? ext : 0.0f);
+            list_full<G, kSphere, MASK>(E, D.n_sphere, D.off_sphere, D.off_md_sphere, D.wbase_sphere, x, y, z, r, rsq, ext,
+                                        ext_wave, hit, mask);
+            list_full<G, kCapsule, MASK>(E, D.n_capsule, D.off_capsule, D.off_md_capsule, D.wbase_capsule, x, y, z, r, rsq,
+                                         ext, ext_wave, hit, mask);
+            list_full<G, kZCapsule, MASK>(E, D.n_zcapsule, D.off_zcapsule, D.off_md_zcapsule, D.wbase_zcapsule, x, y, z, r,
+                                          rsq, ext, ext_wave, hit, mask);
+            list_full<G, kCuboid, MASK>(E, D.n_cuboid, D.off_cuboid, D.off_md_cuboid, D.wbase_cuboid, x, y, z, r, rsq, ext,
+                                        ext_wave, hit, mask);
+            list_full<G, kZCuboid, MASK>(E, D.n_zcuboid, D.off_zcuboid, D.off_md_zcuboid, D.wbase_zcuboid, x, y, z, r, rsq,
+                                         ext, ext_wave, hit, mask);
         }
         hit = hit && active;
         for (uint32_t ci = 0; ci < D.n_capt; ++ci)
@@ -555,7 +668,8 @@ namespace vmv
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
 
-    constexpr int kScratchWords = 2 * kWave + 4;  // per-wave LDS scratch behind the slab: lane list, hit flags, k
+    // per-wave LDS scratch behind the slab: lane list [64], hit flags [64], k [4], candidate words [kMaskWords][64]
+    constexpr int kScratchWords = 2 * kWave + 4 + kMaskWords * kWave;
 
     // One link's environment group (robots/panda.hh:5629-6010): `if (hit(bounding)) { any fine sphere hits }`.
     //
@@ -572,8 +686,6 @@ namespace vmv
     //              max_extent.  Hits are OR-ed back per configuration through LDS flags.
     //   env_flag   this lane's "some fine sphere of my configuration hit".
     // `active` (rake-uniform) only prunes work.  Tab::radius(i) reads the robot's __constant__ radius table.
-    typedef __attribute__((address_space(3))) uint32_t lds_u32;
-
     template <int G, typename Tab>
     __device__ __noinline__ bool
     env_gate(const EnvView E_, lds_cptr slab, lds_ptr scratch_, const int radius_index_, const bool active)
@@ -581,8 +693,19 @@ namespace vmv
         const uint32_t lane = __lane_id();
         const EnvView E{uniform(E_.dev), uniform(E_.lds), uniform(E_.capt0_planes_in_lds)};
         lds_u32 *list = (lds_u32 *) uniform((lds_cptr) scratch_);
-        const bool gate = group_any<G>(
-            env_hit<G>(E, slab[0], slab[kWave], slab[2 * kWave], Tab::radius(uniform(radius_index_)), active));
+        lds_u32 *mask_lane = list + 2 * kWave + 4 + lane;
+        bool own;
+        if (E.dev->masked_fine)
+        {
+#pragma unroll
+            for (int w = 0; w < kMaskWords; ++w) mask_lane[w * kWave] = 0u;
+            own = env_hit<G, 1>(E, slab[0], slab[kWave], slab[2 * kWave], Tab::radius(uniform(radius_index_)), active,
+                                mask_lane);
+        }
+        else
+            own = env_hit<G, 0>(E, slab[0], slab[kWave], slab[2 * kWave], Tab::radius(uniform(radius_index_)), active,
+                                nullptr);
+        const bool gate = group_any<G>(own);
         const uint64_t mask = __ballot(gate);
         list[kWave + lane] = 0u;  // flags
         if (gate) list[__popcll(mask & ((1ull << lane) - 1ull))] = lane;
@@ -602,6 +725,7 @@ namespace vmv
         const int n_fine = uniform(n_fine_), radii_offset = uniform(radii_offset_);
         const int k = (int) uniform(list[2 * kWave]);
         if (k == 0) return;
+        const bool masked = E.dev->masked_fine != 0u;
         lds_cptr wave_slab = uniform(slab - lane);
         const int items = k * n_fine;
         const float inv_k = 1.0f / (float) k;
@@ -615,7 +739,12 @@ namespace vmv
             const int j = act ? (i - s * k) : 0;
             const uint32_t src = list[j];
             lds_cptr p = wave_slab + 3 * (s + 1) * kWave + src;
-            const bool hit = env_hit<G>(E, p[0], p[kWave], p[2 * kWave], Tab::radius(radii_offset + s), act);
+            bool hit;
+            if (masked)
+                hit = env_hit<G, 2>(E, p[0], p[kWave], p[2 * kWave], Tab::radius(radii_offset + s), act,
+                                    list + 2 * kWave + 4 + src);
+            else
+                hit = env_hit<G, 0>(E, p[0], p[kWave], p[2 * kWave], Tab::radius(radii_offset + s), act, nullptr);
             if (hit) flags[src] = 1u;
         }
         wave_lds_sync();
