@@ -367,8 +367,9 @@ def main(models):
         sp = ", ".join(flit(v) for v in m["span"] + [0.0] * (16 - m["dimension"]))
         ds = ", ".join(flit(v) for v in m["descale"] + [0.0] * (16 - m["dimension"]))
         jn = ", ".join('"%s"' % j for j in m["joint_names"])
+        max_bound = max(m["radii"][m["n_spheres"]:])
         host.append(f'    {{"{m["name"]}", {m["dimension"]}, {m["n_spheres"]}, {m["resolution"]}, '
-                    f'{flit(m["min_radius"])}, {flit(m["max_radius"])}, {{{lo}}}, {{{sp}}}, {{{ds}}}, '
+                    f'{flit(m["min_radius"])}, {flit(m["max_radius"])}, {flit(max_bound)}, {{{lo}}}, {{{sp}}}, {{{ds}}}, '
                     f'"{m["end_effector"]}", {{{jn}}}}},')
     host.append("};")
     host.append(f"static const int kNumRobots = {len(models)};")

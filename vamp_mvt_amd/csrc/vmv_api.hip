@@ -10,12 +10,14 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
 
 #include "vmv_capt_build.h"
 #include "vmv_mvt_build.h"
+#include "vmv_grid_build.h"
 #include "vmv_common.h"
 
 // ---------------------------------------------------------------------------------------------------------
@@ -25,7 +27,7 @@ struct vmv_robot_info
 {
     const char *name;
     int dimension, n_spheres, resolution;
-    float min_radius, max_radius;
+    float min_radius, max_radius, max_bounding_radius;
     float lower[16], span[16], descale[16];
     const char *end_effector;
     const char *joint_names[16];
@@ -137,7 +139,7 @@ struct vmv_env
 
     bool finalized = false;
     int device = -1;
-    vmv::EnvLaunch launch{};  // host + device copies of the kernel-side description
+    vmv::EnvLaunch launch[8]{};  // per robot: host + device copies of the kernel-side description (grids differ)
     std::vector<void *> allocations;
 };
 
@@ -399,8 +401,8 @@ extern "C"
 
         // pack the LDS primitive block (record layouts: vmv_device.h)
         std::vector<float> block;
-        vmv::EnvDev &D = env->launch.host;
-        D = vmv::EnvDev{};
+        vmv::EnvDev D_base{};
+        vmv::EnvDev &D = D_base;
         D.n_sphere = (uint32_t) env->spheres.size();
         D.off_sphere = (uint32_t) block.size();
         for (const auto &s : env->spheres) block.insert(block.end(), {s.x, s.y, s.z, s.r, s.min_d, 0.f, 0.f, 0.f});
@@ -497,9 +499,39 @@ extern "C"
             d.r_point = m.r_point;
             d.grid_width = m.grid_width;
         }
+        // broad-phase grid of the gate pass, one per robot (its reach is the robot's largest bounding radius)
+        std::vector<vmv::GridPrim> gp;
+        if (D.masked_fine)
         {
-            std::vector<vmv::EnvDev> one(1, D);
-            if ((rc = upload(env, one, &env->launch.d_env)) != VMV_OK) return rc;
+            auto add = [&](int type, const float *p, uint32_t wbase, size_t i)
+            { gp.push_back(vmv::GridPrim{type, p, wbase + (uint32_t) (i / 32), (uint32_t) (i % 32)}); };
+            for (size_t i = 0; i < env->spheres.size(); ++i) add(0, &env->spheres[i].x, D.wbase_sphere, i);
+            for (size_t i = 0; i < env->capsules.size(); ++i) add(1, env->capsules[i].p, D.wbase_capsule, i);
+            for (size_t i = 0; i < env->z_capsules.size(); ++i) add(2, env->z_capsules[i].p, D.wbase_zcapsule, i);
+            for (size_t i = 0; i < env->cuboids.size(); ++i) add(3, env->cuboids[i].p, D.wbase_cuboid, i);
+            for (size_t i = 0; i < env->z_cuboids.size(); ++i) add(4, env->z_cuboids[i].p, D.wbase_zcuboid, i);
+        }
+        uint32_t total_words = 0;
+        for (uint32_t n : {D.n_sphere, D.n_capsule, D.n_zcapsule, D.n_cuboid, D.n_zcuboid}) total_words += (n + 31u) / 32u;
+        const bool use_grid = std::getenv("VMV_NO_GRID") == nullptr;
+        for (int r = 0; r < kNumRobots; ++r)
+        {
+            vmv::EnvDev Dr = D_base;
+            vmv::GridArrays grid;
+            if (use_grid && !gp.empty() && vmv::build_grid(gp, total_words, (double) kRobots[r].max_bounding_radius, grid))
+            {
+                if ((rc = upload(env, grid.cells, &Dr.grid)) != VMV_OK) return rc;
+                for (int k = 0; k < 3; ++k)
+                {
+                    Dr.grid_dims[k] = grid.dims[k];
+                    Dr.grid_origin[k] = grid.origin[k];
+                }
+                Dr.grid_words = grid.words;
+                Dr.grid_inv_cell = grid.inv_cell;
+            }
+            env->launch[r].host = Dr;
+            std::vector<vmv::EnvDev> one(1, Dr);
+            if ((rc = upload(env, one, &env->launch[r].d_env)) != VMV_OK) return rc;
         }
         env->finalized = true;
         return VMV_OK;
@@ -576,7 +608,7 @@ extern "C"
         if (!env || !d_q || !d_bits) return VMV_ERR_INVALID_ARGUMENT;
         if (!env->finalized) return VMV_ERR_NOT_FINALIZED;
         if (n == 0) return VMV_OK;
-        return kLaunchers[robot]->validate(env->launch, d_q, n, d_bits, static_cast<hipStream_t>(stream), 3);
+        return kLaunchers[robot]->validate(env->launch[robot], d_q, n, d_bits, static_cast<hipStream_t>(stream), 3);
     }
 
     int vmv_validate_batch_env(int robot, const vmv_env *env, const float *d_q, size_t n, uint64_t *d_bits, void *stream)
@@ -585,7 +617,7 @@ extern "C"
         if (!env || !d_q || !d_bits) return VMV_ERR_INVALID_ARGUMENT;
         if (!env->finalized) return VMV_ERR_NOT_FINALIZED;
         if (n == 0) return VMV_OK;
-        return kLaunchers[robot]->validate(env->launch, d_q, n, d_bits, static_cast<hipStream_t>(stream), 1);
+        return kLaunchers[robot]->validate(env->launch[robot], d_q, n, d_bits, static_cast<hipStream_t>(stream), 1);
     }
 
     int vmv_validate_batch_self(int robot, const float *d_q, size_t n, uint64_t *d_bits, void *stream)
@@ -603,7 +635,7 @@ extern "C"
         if (!env || !d_a || !d_b || !d_bits) return VMV_ERR_INVALID_ARGUMENT;
         if (!env->finalized) return VMV_ERR_NOT_FINALIZED;
         if (n == 0) return VMV_OK;
-        return kLaunchers[robot]->validate_motion(env->launch, d_a, d_b, n, d_bits, static_cast<hipStream_t>(stream));
+        return kLaunchers[robot]->validate_motion(env->launch[robot], d_a, d_b, n, d_bits, static_cast<hipStream_t>(stream));
     }
 
     int vmv_fk_batch(int robot, const float *d_q, size_t n, float *d_out, void *stream)

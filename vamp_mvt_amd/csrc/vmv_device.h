@@ -175,6 +175,11 @@ namespace vmv
         uint32_t off_md_sphere, off_md_capsule, off_md_zcapsule, off_md_cuboid, off_md_zcuboid;  // min_distance arrays
         // candidate words (32 primitives each) per list: first word index, and whether all lists fit kMaskWords
         uint32_t wbase_sphere, wbase_capsule, wbase_zcapsule, wbase_cuboid, wbase_zcuboid, masked_fine;
+        // broad-phase grid of the gate pass (vmv_grid_build.h; robot specific: built for the robot's largest bounding
+        // radius): candidate words per cell, or grid == nullptr -> counted loops over the whole lists
+        const uint32_t *grid;
+        uint32_t grid_dims[3], grid_words;
+        float grid_origin[3], grid_inv_cell;
         uint32_t n_capt;
         uint32_t capt0_n_tests;  // size of capt[0].tests (candidate for LDS staging behind the primitive block)
         uint32_t n_mvt;
@@ -660,6 +665,79 @@ namespace vmv
 #undef D
     }
 
+    // One sorted list in the gate pass, driven by the broad-phase grid: this lane evaluates the reference's exact
+    // predicates on the candidates of its own cell only, and records the fine-phase candidates (kCandidateMargin)
+    // among them.  Lanes walk their own candidate bits; the loop runs until the busiest lane is done.
+    template <int T>
+    __device__ __forceinline__ void list_grid(const EnvView &E, const uint32_t n, const uint32_t off, const uint32_t wbase,
+                                              const gu_cptr cell, float x, float y, float z, float r, float rsq, float ext,
+                                              bool inside, bool &hit, lds_u32 *mask_lane)
+    {
+        if (n == 0) return;
+        constexpr int REC = PrimTraits<T>::rec;
+        const uint32_t words = (n + 31) / 32;
+        for (uint32_t w = 0; w < words; ++w)
+        {
+            uint32_t m = inside ? cell[wbase + w] : 0u;
+            uint32_t fine = 0u;
+            while (wave_any(m != 0u))
+            {
+                if (m != 0u)
+                {
+                    const uint32_t bit = (uint32_t) __ffs((int) m) - 1u;
+                    m &= m - 1u;
+                    lds_cptr rec = E.lds + off + (w * 32u + bit) * REC;
+                    float v, md, reach;
+                    prim_eval<T>(rec, x, y, z, r, rsq, v, md, reach);
+                    hit |= neg(md - ext) && neg(v);
+                    const float tau = reach * (2.0f * kCandidateMargin) + kCandidateMargin * kCandidateMargin;
+                    fine |= (v < tau) ? (1u << bit) : 0u;
+                }
+            }
+            mask_lane[(wbase + w) * kWave] = fine;
+        }
+    }
+
+    // Gate pass of one bounding sphere through the broad-phase grid (same answer as env_hit<G, 1>).
+    template <int G>
+    __device__ __forceinline__ bool
+    env_hit_grid(const EnvView &E, float x, float y, float z, float r, bool active, lds_u32 *mask_lane)
+    {
+        const env_cptr Dp = E.dev;
+#define D (*Dp)
+        const float ext = group_max<G>(sqrtf(dot3(x, y, z, x, y, z)) + r);
+        const float rsq = r * r;
+        // this lane's cell; outside the grid box nothing can be touched (vmv_grid_build.h)
+        const float fx = (x - D.grid_origin[0]) * D.grid_inv_cell, fy = (y - D.grid_origin[1]) * D.grid_inv_cell,
+                    fz = (z - D.grid_origin[2]) * D.grid_inv_cell;
+        const bool inside = active && fx >= 0.0f && fy >= 0.0f && fz >= 0.0f && fx < (float) D.grid_dims[0] &&
+                            fy < (float) D.grid_dims[1] && fz < (float) D.grid_dims[2];
+        const uint32_t ix = inside ? (uint32_t) fx : 0u, iy = inside ? (uint32_t) fy : 0u, iz = inside ? (uint32_t) fz : 0u;
+        const gu_cptr cell = (gu_cptr) D.grid + ((size_t) (ix * D.grid_dims[1] + iy) * D.grid_dims[2] + iz) * D.grid_words;
+        bool hit = false;
+        list_grid<kSphere>(E, D.n_sphere, D.off_sphere, D.wbase_sphere, cell, x, y, z, r, rsq, ext, inside, hit, mask_lane);
+        list_grid<kCapsule>(E, D.n_capsule, D.off_capsule, D.wbase_capsule, cell, x, y, z, r, rsq, ext, inside, hit, mask_lane);
+        list_grid<kZCapsule>(E, D.n_zcapsule, D.off_zcapsule, D.wbase_zcapsule, cell, x, y, z, r, rsq, ext, inside, hit,
+                             mask_lane);
+        list_grid<kCuboid>(E, D.n_cuboid, D.off_cuboid, D.wbase_cuboid, cell, x, y, z, r, rsq, ext, inside, hit, mask_lane);
+        list_grid<kZCuboid>(E, D.n_zcuboid, D.off_zcuboid, D.wbase_zcuboid, cell, x, y, z, r, rsq, ext, inside, hit, mask_lane);
+        hit = hit && active;
+        for (uint32_t ci = 0; ci < D.n_capt; ++ci)
+        {
+            const bool act = active && !hit;
+            if (!wave_any(act)) break;
+            hit |= capt_collides(Dp, ci, E.lds + D.n_floats, (ci == 0) ? E.capt0_planes_in_lds : 0u, x, y, z, r, act);
+        }
+        for (uint32_t mi = 0; mi < D.n_mvt; ++mi)
+        {
+            const bool act = active && !hit;
+            if (!wave_any(act)) break;
+            hit |= mvt_collides(Dp, mi, x, y, z, r, act);
+        }
+        return hit;
+#undef D
+    }
+
     __device__ __forceinline__ void wave_lds_sync()
     {
         // same-wave LDS hand-off (DS ops of one wave retire in order; this pins the compiler's order too)
@@ -695,7 +773,10 @@ namespace vmv
         lds_u32 *list = (lds_u32 *) uniform((lds_cptr) scratch_);
         lds_u32 *mask_lane = list + 2 * kWave + 4 + lane;
         bool own;
-        if (E.dev->masked_fine)
+        if (E.dev->masked_fine && E.dev->grid != nullptr)
+            own = env_hit_grid<G>(E, slab[0], slab[kWave], slab[2 * kWave], Tab::radius(uniform(radius_index_)), active,
+                                  mask_lane);
+        else if (E.dev->masked_fine)
         {
 #pragma unroll
             for (int w = 0; w < kMaskWords; ++w) mask_lane[w * kWave] = 0u;
