@@ -1045,6 +1045,11 @@ static int sphere_environment_in_collision(const vo_env *e, const float *sx, con
     return 0;
 }
 
+int vo_sphere_environment_in_collision(const vo_env *e, const float c[3], float r)
+{
+    return sphere_environment_in_collision(e, &c[0], &c[1], &c[2], r, 1);
+}
+
 /* ------------------------------------------------------------------------- */
 /* L1b: robots (generated FK + tables)                                        */
 /* ------------------------------------------------------------------------- */

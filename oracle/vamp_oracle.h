@@ -93,6 +93,9 @@ int vo_capt_collides(const vo_env *e, size_t index, const float c[3], float r);
 int vo_capt_collides_simd(const vo_env *e, size_t index, const float *cx, const float *cy, const float *cz,
                           const float *r, int lanes);
 
+/* sphere_environment_in_collision (collision/validity.hh:47-158) for one sphere (a rake of one lane); 1 = collides */
+int vo_sphere_environment_in_collision(const vo_env *e, const float c[3], float r);
+
 /* robots */
 int vo_robot_id(const char *name); /* -1 if unknown */
 size_t vo_robot_dimension(int robot);

@@ -79,6 +79,7 @@ class Oracle:
         L.vo_env_capt_view.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(CaptView)]
         L.vo_capt_collides.argtypes = [ctypes.c_void_p, ctypes.c_size_t, _fp, ctypes.c_float]
         L.vo_capt_collides_simd.argtypes = [ctypes.c_void_p, ctypes.c_size_t, _fp, _fp, _fp, _fp, ctypes.c_int]
+        L.vo_sphere_environment_in_collision.argtypes = [ctypes.c_void_p, _fp, ctypes.c_float]
         L.vo_robot_id.argtypes = [ctypes.c_char_p]
         for fn in ("vo_robot_dimension", "vo_robot_n_spheres", "vo_robot_n_total_spheres", "vo_robot_resolution"):
             getattr(L, fn).argtypes = [ctypes.c_int]

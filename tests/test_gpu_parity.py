@@ -56,6 +56,27 @@ def test_validate_motion_batch_bit_exact(vamp, oracle, name, kind):
 
 
 @pytest.mark.parametrize("name", ROBOTS)
+@pytest.mark.parametrize("kind", ["empty", "shell64"])
+def test_clustered_waves_bit_exact(vamp, oracle, name, kind):
+    """Adversarial for the kernels' in-wave work lists: every lane of a wave holds (nearly) the same configuration,
+    so whichever gate fires, fires on all 64 lanes at once (fullest item lists, all rounds, all flush paths)."""
+    env, oenv = make_env(kind, oracle, name)
+    rid, base = uniform_configs(oracle, name, 96, seed=11)
+    rng = np.random.default_rng(12)
+    q = np.repeat(base, 64, axis=0)
+    q[64 * 32:] += rng.normal(0, 2e-3, q[64 * 32:].shape).astype(np.float32)  # second third: tiny jitter per lane
+    got = getattr(vamp, name).validate_batch(q, env)
+    want = oracle.validate_batch(rid, oenv, q, threads=8)
+    assert np.array_equal(got, want)
+    # the same clusters as edges: 8 identical rakes per wave, moving together
+    a = q[::8][:768]
+    b = (a + np.repeat(rng.normal(0, 0.3, (a.shape[0] // 8, a.shape[1])), 8, axis=0)).astype(np.float32)
+    got_e = getattr(vamp, name).validate_motion_batch(a, b, env)
+    want_e = oracle.validate_motion_batch(rid, oenv, a, b)
+    assert np.array_equal(got_e, want_e)
+
+
+@pytest.mark.parametrize("name", ROBOTS)
 def test_fk_bit_exact_vs_golden_and_oracle(vamp, oracle, golden_dir, name):
     g = np.load(os.path.join(golden_dir, f"fk_{name}.npz"))
     n_fine = int(g["n_fine"])

@@ -101,8 +101,57 @@ def f32(x):
     return np.float32(x)
 
 
+def eval_tape(m, q):
+    """float64 evaluation of the model's op tape for configurations q[N][dim] -> sphere centres [N][n_total][3]
+    (statistics for code-shape decisions only; the device code evaluates the tape itself)."""
+    vals = [None] * len(m["ops"])
+    for i, (op, a, b) in enumerate(m["ops"]):
+        if op == "in":
+            v = q[:, a]
+        elif op == "sin":
+            v = np.sin(vals[a])
+        elif op == "cos":
+            v = np.cos(vals[a])
+        elif op == "neg":
+            v = -vals[a]
+        elif op == "mul":
+            v = vals[a] * vals[b]
+        elif op == "add":
+            v = vals[a] + vals[b]
+        elif op == "sub":
+            v = vals[a] - vals[b]
+        elif op == "cmul":
+            v = a * vals[b]
+        elif op == "cadd":
+            v = a + vals[b]
+        else:
+            raise ValueError(op)
+        vals[i] = v
+    out = np.zeros((q.shape[0], len(m["outputs"]), 3))
+    for s, o in enumerate(m["outputs"]):
+        for k, (kind, v) in enumerate(o):
+            out[:, s, k] = vals[v] if kind == "op" else v
+    return out
+
+
+def gate_rates(m, n=4096, seed=0):
+    """Share of uniformly random configurations whose bounding-pair gate fires, per self-collision group."""
+    rng = np.random.default_rng(seed)
+    q = np.array(m["lower"]) + np.array(m["span"]) * rng.random((n, m["dimension"]))
+    c = eval_tape(m, q)
+    r = np.array(m["radii"])
+    return [float((np.linalg.norm(c[:, g["bound_a"]] - c[:, g["bound_b"]], axis=1) < r[g["bound_a"]] + r[g["bound_b"]]).mean())
+            for g in m["self_groups"]]
+
+
 SELF_DEAL_MAX_A = 40  # A-side spheres kept in registers for the re-dealt self-collision form
+SELF_BLOCKS = {"panda": 3, "ur5": 3}  # workgroups per CU the self kernel is compiled for (512 / blocks VGPRs per lane)
+SELF_DENSE_RATE = 0.5   # groups whose bounding-pair gate fires for at least this share of uniform configurations ...
+SELF_DENSE_MIN_A = 3    # ... and whose A side is at least this large use the pre-test + compaction form
+SPARSE_BATCH = 8        # sparse groups merged per item list (the list holds SPARSE_BATCH * 64 entries = CHUNK * 64)
+SELF_MARGIN = 1e-4      # metres; enclosure of fine spheres by bounding spheres is asserted to 2e-6 by tools/robot_trace.py
 CHUNK = 8  # fine spheres staged in the LDS slab at a time (slab = 1 bounding + CHUNK fine spheres per wave)
+assert SPARSE_BATCH <= 8 and CHUNK <= 8  # vmv::kSelfScratchWords holds 8 * 64 list entries
 
 
 def emit_robot(m):
@@ -132,6 +181,7 @@ def emit_robot(m):
     L.append(f"    constexpr int kNSpheres = {m['n_spheres']};")
     L.append(f"    constexpr int kResolution = {m['resolution']};")
     L.append(f"    constexpr int kSlabSpheres = {slab_spheres};  // bounding sphere + one chunk of fine spheres")
+    L.append(f"    constexpr int kNRadii = {len(radii_tab)};")
     L.append(f"    __constant__ float kRadii[{len(radii_tab)}] = {{" + ", ".join(flit(v) for v in radii_tab) + "};")
     L.append("    struct Tab")
     L.append("    {")
@@ -149,7 +199,7 @@ def emit_robot(m):
     L.append("    {")
     L.append("        bool bad = skip;")
     L.append("        // per-wave scratch words live right behind the sphere slab")
-    L.append("        const vmv::lds_ptr scratch = slab - __lane_id() + kSlabSpheres * 3 * vmv::kWave;")
+    L.append("        const vmv::lds_ptr scratch = slab - __lane_id() + kSlabSpheres * 3 * vmv::kRow;")
     em = Emitter(m)
     for ln in links:
         g = env_by_link[ln]
@@ -160,7 +210,7 @@ def emit_robot(m):
 
         def stage(slot, s, indent):
             for k in range(3):
-                em.lines.append(f"{indent}slab[{3 * slot + k} * vmv::kWave] = {em.coord(s, k)};")
+                em.lines.append(f"{indent}slab[{3 * slot + k} * vmv::kRow] = {em.coord(s, k)};")
 
         stage(0, g["bound"], "        ")
         for si, s in enumerate(chunks[0]):
@@ -199,20 +249,36 @@ def emit_robot(m):
         cur_n += link_size[ln]
     if cur:
         batches.append(cur)
+    rates = gate_rates(m)
+    dense_ids = {id(sg) for sg, r in zip(m["self_groups"], rates)
+                 if r >= SELF_DENSE_RATE and len({p[0] for p in sg["pairs"]}) >= SELF_DENSE_MIN_A}
     L.append("    // Self-collision half of Robot::fkcc<rake> (\"robot self-collisions\").")
-    L.append("    // Groups (A, B) run when B is the current link.  Gates (bounding pair) are per lane; the fine pairs of the")
-    L.append("    // few rakes whose gate fired are re-dealt over the 64 lanes as (passing lane, B sphere) items: B's")
-    L.append("    // sphere comes from the LDS slab column of the lane the item belongs to, A's spheres from that lane's")
-    L.append("    // registers through ds_bpermute (__shfl); hits return through LDS flags.")
+    L.append("    // Groups (A, B) run when B is the current link; gates (bounding pair) are per lane, exact.")
+    L.append("    //  * sparse groups (gate rarely fires): the (passing lane, group) pairs of ALL sparse groups of this B are")
+    L.append("    //    listed together and their fine pairs re-dealt over the 64 lanes as (entry, B sphere) items - one LDS")
+    L.append("    //    round trip per chunk instead of one per group; B's sphere comes from the LDS slab column of the owning")
+    L.append("    //    lane, A's spheres from that lane's registers through ds_bpermute (__shfl);")
+    L.append("    //  * dense groups (gate fires for most configurations; chosen here from sampled gate rates): every lane")
+    L.append("    //    pre-tests its own B spheres against A's bounding sphere and its A spheres against B's (a fine pair can")
+    L.append("    //    only overlap if both reach; margin kSelfMargin >> fp32 effects, enclosure asserted by the tracer), the")
+    L.append("    //    surviving (lane, B sphere) items are compacted in LDS and only those run the exact pair tests, on the")
+    L.append("    //    A spheres that are candidates for some item of the batch.  Pruning only; answers are unchanged.")
+    L.append("    // Hits return through LDS flags.  Every __shfl runs with all lanes enabled (ds_bpermute reads 0 from a")
+    L.append("    // disabled source lane).")
     L.append(f"    // {len(batches)} pass(es) over the chain; each keeps one batch of A links in registers.")
     L.append("    template <int G>")
-    L.append("    __device__ __forceinline__ bool fkcc_self(const float (&q)[kDim], vmv::lds_ptr slab, const bool skip)")
+    L.append("    __device__ __forceinline__ bool")
+    L.append("    fkcc_self(const float (&q)[kDim], vmv::lds_ptr slab, const vmv::lds_cptr radii_, const bool skip)")
     L.append("    {")
     L.append("        bool bad = skip;")
     L.append("        const unsigned lane = __lane_id();")
     L.append("        const vmv::lds_cptr wave_slab = vmv::uniform((vmv::lds_cptr) (slab - lane));")
-    L.append("        vmv::lds_u32 *const list = (vmv::lds_u32 *) (slab - lane + kSlabSpheres * 3 * vmv::kWave);")
+    L.append("        const vmv::lds_cptr radii = vmv::uniform(radii_);")
+    L.append("        vmv::lds_u32 *const list = (vmv::lds_u32 *) (slab - lane + kSlabSpheres * 3 * vmv::kRow);")
     L.append("        vmv::lds_u32 *const flags = list + vmv::kWave;")
+    L.append("        vmv::lds_u32 *const cand = list + 2 * vmv::kWave + 4;  // A-side candidate word per owner lane")
+    L.append(f"        vmv::lds_u32 *const list2 = cand + vmv::kWave;        // item lists: (owner lane | tag << 6), <= {max(CHUNK, SPARSE_BATCH)} * 64 entries")
+    L.append(f"        static_assert(vmv::kSelfScratchWords >= 3 * vmv::kWave + 4 + {CHUNK} * vmv::kWave, \"self-collision scratch\");")
     for bi, batch in enumerate(batches):
         batch_set = set(batch)
         L.append(f"        {{  // pass {bi}: A in {{{', '.join(batch)}}}")
@@ -251,48 +317,127 @@ def emit_robot(m):
                     f"{I}const bool {gn} = vmv::group_any<G>(vmv::neg(vmv::sql2_3({em.coord(ba, 0)}, {em.coord(ba, 1)}, "
                     f"{em.coord(ba, 2)}, {em.coord(bb, 0)}, {em.coord(bb, 1)}, {em.coord(bb, 2)}) - {flit(float(f32(rs * rs)))}))"
                     f" && !bad;  // {sg['a']} vs. {ln}")
+            sparse = [gi for gi, sg in enumerate(groups) if id(sg) not in dense_ids]
+            dense = [gi for gi, sg in enumerate(groups) if id(sg) in dense_ids]
             em.lines.append(f"{I}if (vmv::wave_any(" + " || ".join(gate_names) + "))")
             em.lines.append(f"{I}{{")
             em.lines.append(f"{I}    flags[lane] = 0u;")
+            J = I + "    "
+
+            def a_coord(s):
+                cs = []
+                for k in range(3):
+                    kind, v = m["outputs"][s][k]
+                    cs.append(f"__shfl({em.prefix}{v}, (int) src)" if kind == "op" else flit(v))
+                return cs
+
+            def b_fetch(K, off):
+                em.lines.append(f"{K}const vmv::lds_cptr p = wave_slab + 3 * t * vmv::kRow + src;")
+                em.lines.append(f"{K}const float bx = p[0], by = p[vmv::kRow], bz = p[2 * vmv::kRow];")
+                em.lines.append(f"{K}const float rb = radii[{off} + t];")
+
+            def pair_tests(K, a_sph, acc, guard=None):
+                for ai, s in enumerate(a_sph):
+                    cs = a_coord(s)
+                    if guard:
+                        em.lines.append(f"{K}if (vmv::wave_any((ma & {1 << ai}u) != 0u))")
+                    em.lines.append(f"{K}{{")
+                    em.lines.append(f"{K}    const float rs = {flit(radii[s])} + rb;")
+                    em.lines.append(f"{K}    {acc} |= vmv::neg(vmv::sql2_3({cs[0]}, {cs[1]}, {cs[2]}, bx, by, bz) - rs * rs);")
+                    em.lines.append(f"{K}}}")
+
+            # dense groups: the owners' A-side candidate words (A spheres that reach B's bounding sphere)
+            for gi in dense:
+                sg = groups[gi]
+                a_sph = sorted({p[0] for p in sg["pairs"]})
+                em.lines.append(f"{J}unsigned cand_{gate_names[gi]} = 0u;")
+                em.lines.append(f"{J}if (vmv::wave_any({gate_names[gi]}))")
+                em.lines.append(f"{J}{{")
+                for ai, s in enumerate(a_sph):
+                    rs = float(f32(radii[s])) + float(f32(radii[bb])) + SELF_MARGIN
+                    em.lines.append(
+                        f"{J}    cand_{gate_names[gi]} |= vmv::neg(vmv::sql2_3({em.coord(s, 0)}, {em.coord(s, 1)}, {em.coord(s, 2)}, "
+                        f"{em.coord(bb, 0)}, {em.coord(bb, 1)}, {em.coord(bb, 2)}) - {flit(float(f32(rs * rs)))}) ? {1 << ai}u : 0u;")
+                em.lines.append(f"{J}}}")
             done = 0
             for ci, ch in enumerate(chunks):
+                off = radii_off[ln] + 1 + done
                 for si, s in enumerate(ch):
                     for k in range(3):
-                        em.lines.append(f"{I}    slab[{3 * si + k} * vmv::kWave] = {em.coord(s, k)};")
-                em.lines.append(f"{I}    vmv::wave_lds_sync();")
-                for gi, sg in enumerate(groups):
+                        em.lines.append(f"{J}slab[{3 * si + k} * vmv::kRow] = {em.coord(s, k)};")
+                em.lines.append(f"{J}vmv::wave_lds_sync();")
+                # the merged entry list holds at most SPARSE_BATCH * 64 (lane, group) entries
+                for sb in range(0, len(sparse), SPARSE_BATCH):
+                    batch_groups = sparse[sb:sb + SPARSE_BATCH]
+                    em.lines.append(f"{J}if (vmv::wave_any(" + " || ".join(gate_names[gi] for gi in batch_groups) + f"))  // sparse groups, chunk {ci}")
+                    em.lines.append(f"{J}{{")
+                    K = J + "    "
+                    em.lines.append(f"{K}int k = 0;")
+                    for li, gi in enumerate(batch_groups):
+                        em.lines.append(f"{K}k = vmv::deal_append(list2, k, {gate_names[gi]}, {li}u << 6);  // {groups[gi]['a']}")
+                    em.lines.append(f"{K}vmv::wave_lds_sync();")
+                    em.lines.append(f"{K}const int items = k * {len(ch)};")
+                    em.lines.append(f"{K}const float inv_k = 1.0f / (float) k;")
+                    em.lines.append(f"{K}for (int base = 0; base < items; base += vmv::kWave)")
+                    em.lines.append(f"{K}{{")
+                    K2 = K + "    "
+                    em.lines.append(f"{K2}const int i = base + (int) lane;")
+                    em.lines.append(f"{K2}const bool act = i < items;")
+                    em.lines.append(f"{K2}const int t = act ? (int) (((float) i + 0.5f) * inv_k) : 0;")
+                    em.lines.append(f"{K2}const int j = act ? (i - t * k) : 0;")
+                    em.lines.append(f"{K2}const unsigned e = list2[j];")
+                    em.lines.append(f"{K2}const unsigned src = e & 63u;")
+                    em.lines.append(f"{K2}const unsigned grp = act ? (e >> 6) : ~0u;")
+                    b_fetch(K2, off)
+                    em.lines.append(f"{K2}bool h = false;")
+                    for li, gi in enumerate(batch_groups):
+                        sg = groups[gi]
+                        a_sph = sorted({p[0] for p in sg["pairs"]})
+                        b_sph = sorted({p[1] for p in sg["pairs"]})
+                        assert b_sph == fine and sg["pairs"] == [[s, t] for s in a_sph for t in b_sph]
+                        em.lines.append(f"{K2}if (vmv::wave_any(grp == {li}u))  // {sg['a']} vs. {ln}")
+                        em.lines.append(f"{K2}{{")
+                        em.lines.append(f"{K2}    bool hg = false;")
+                        pair_tests(K2 + "    ", a_sph, "hg")
+                        em.lines.append(f"{K2}    h |= hg && (grp == {li}u);")
+                        em.lines.append(f"{K2}}}")
+                    em.lines.append(f"{K2}if (h) flags[src] = 1u;")
+                    em.lines.append(f"{K}}}")
+                    em.lines.append(f"{K}vmv::wave_lds_sync();")
+                    em.lines.append(f"{J}}}")
+                for gi in dense:
+                    sg = groups[gi]
+                    gn = gate_names[gi]
+                    ba = sg["bound_a"]
                     a_sph = sorted({p[0] for p in sg["pairs"]})
                     b_sph = sorted({p[1] for p in sg["pairs"]})
                     assert b_sph == fine and sg["pairs"] == [[s, t] for s in a_sph for t in b_sph]
-                    J = I + "    "
-                    em.lines.append(f"{J}if (vmv::wave_any({gate_names[gi]}))  // {sg['a']} vs. {ln}, chunk {ci}")
+                    em.lines.append(f"{J}if (vmv::wave_any({gn}))  // dense: {sg['a']} vs. {ln}, chunk {ci}")
                     em.lines.append(f"{J}{{")
-                    em.lines.append(f"{J}    const int k = vmv::deal_list(list, {gate_names[gi]});")
-                    em.lines.append(f"{J}    const int items = k * {len(ch)};")
-                    em.lines.append(f"{J}    const float inv_k = 1.0f / (float) k;")
-                    em.lines.append(f"{J}    for (int base = 0; base < items; base += vmv::kWave)")
-                    em.lines.append(f"{J}    {{")
-                    em.lines.append(f"{J}        const int i = base + (int) lane;")
-                    em.lines.append(f"{J}        const bool act = i < items;")
-                    em.lines.append(f"{J}        const int t = act ? (int) (((float) i + 0.5f) * inv_k) : 0;")
-                    em.lines.append(f"{J}        const int j = act ? (i - t * k) : 0;")
-                    em.lines.append(f"{J}        const unsigned src = list[j];")
-                    em.lines.append(f"{J}        const vmv::lds_cptr p = wave_slab + 3 * t * vmv::kWave + src;")
-                    em.lines.append(f"{J}        const float bx = p[0], by = p[vmv::kWave], bz = p[2 * vmv::kWave];")
-                    em.lines.append(f"{J}        const float rb = kRadii[{radii_off[ln] + 1 + done} + t];")
-                    em.lines.append(f"{J}        bool h = false;")
-                    for s in a_sph:
-                        cs = []
-                        for k in range(3):
-                            kind, v = m["outputs"][s][k]
-                            cs.append(f"__shfl({em.prefix}{v}, (int) src)" if kind == "op" else flit(v))
-                        em.lines.append(f"{J}        {{")
-                        em.lines.append(f"{J}            const float rs = {flit(radii[s])} + rb;")
-                        em.lines.append(f"{J}            h |= vmv::neg(vmv::sql2_3({cs[0]}, {cs[1]}, {cs[2]}, bx, by, bz) - rs * rs);")
-                        em.lines.append(f"{J}        }}")
-                    em.lines.append(f"{J}        if (h && act) flags[src] = 1u;")
-                    em.lines.append(f"{J}    }}")
-                    em.lines.append(f"{J}    vmv::wave_lds_sync();")
+                    K = J + "    "
+                    em.lines.append(f"{K}cand[lane] = cand_{gn};")
+                    em.lines.append(f"{K}int n2 = 0;")
+                    for si, s in enumerate(ch):
+                        rs = float(f32(radii[ba])) + SELF_MARGIN + float(f32(radii[s]))
+                        em.lines.append(
+                            f"{K}n2 = vmv::deal_append(list2, n2, {gn} && vmv::neg(vmv::sql2_3({em.coord(ba, 0)}, {em.coord(ba, 1)}, "
+                            f"{em.coord(ba, 2)}, {em.coord(s, 0)}, {em.coord(s, 1)}, {em.coord(s, 2)}) - {flit(float(f32(rs * rs)))}), {si}u << 6);")
+                    em.lines.append(f"{K}vmv::wave_lds_sync();")
+                    em.lines.append(f"{K}for (int base = 0; base < n2; base += vmv::kWave)")
+                    em.lines.append(f"{K}{{")
+                    K2 = K + "    "
+                    em.lines.append(f"{K2}const int i = base + (int) lane;")
+                    em.lines.append(f"{K2}const bool act = i < n2;")
+                    em.lines.append(f"{K2}const unsigned e = list2[act ? i : 0];")
+                    em.lines.append(f"{K2}const unsigned src = e & 63u;")
+                    em.lines.append(f"{K2}const int t = (int) (e >> 6);")
+                    b_fetch(K2, off)
+                    em.lines.append(f"{K2}const unsigned ma = act ? cand[src] : 0u;")
+                    em.lines.append(f"{K2}bool h = false;")
+                    pair_tests(K2, a_sph, "h", guard=True)
+                    em.lines.append(f"{K2}if (h && act) flags[src] = 1u;")
+                    em.lines.append(f"{K}}}")
+                    em.lines.append(f"{K}vmv::wave_lds_sync();")
                     em.lines.append(f"{J}}}")
                 done += len(ch)
             em.lines.append(f"{I}    bad |= vmv::group_any<G>(flags[lane] != 0u);")
@@ -322,6 +467,8 @@ def emit_robot(m):
     L.append(f"    static constexpr int kNSpheres = {n}::kNSpheres;")
     L.append(f"    static constexpr int kResolution = {n}::kResolution;")
     L.append(f"    static constexpr int kSlabSpheres = {n}::kSlabSpheres;")
+    L.append(f"    static constexpr int kNRadii = {n}::kNRadii;")
+    L.append(f"    static constexpr int kSelfBlocks = {SELF_BLOCKS.get(n, 2)};  // workgroups per CU the self-collision kernel is compiled for")
     L.append("    template <int G>")
     L.append("    static __device__ __forceinline__ bool")
     L.append("    fkcc_env(const vmv::EnvView &E, const float (&q)[kDim], vmv::lds_ptr slab, const bool skip)")
@@ -330,9 +477,9 @@ def emit_robot(m):
     L.append("    }")
     L.append("    template <int G>")
     L.append("    static __device__ __forceinline__ bool")
-    L.append("    fkcc_self(const float (&q)[kDim], vmv::lds_ptr slab, const bool skip)")
+    L.append("    fkcc_self(const float (&q)[kDim], vmv::lds_ptr slab, const vmv::lds_cptr radii, const bool skip)")
     L.append("    {")
-    L.append(f"        return {n}::fkcc_self<G>(q, slab, skip);")
+    L.append(f"        return {n}::fkcc_self<G>(q, slab, radii, skip);")
     L.append("    }")
     L.append("    static __device__ __forceinline__ void sphere_fk(const float (&q)[kDim], float4 *out)")
     L.append("    {")

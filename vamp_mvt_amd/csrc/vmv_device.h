@@ -14,6 +14,10 @@
 namespace vmv
 {
     constexpr int kWave = 64;  // gfx950 wavefront
+    // Row stride (words) of the per-wave sphere slab: row r of lane l sits at r * kRow + l.  The odd stride puts the
+    // rows of one lane on different LDS banks (ds_read_b32 banks = word mod 32), so re-dealt items that read
+    // different spheres of the same configuration do not collide (a stride of 64 made that an N-way conflict).
+    constexpr int kRow = kWave + 1;
 
     // explicit LDS address space: pointers that cross a (non-inlined) call keep ds_read/ds_write addressing
     using lds_float = __attribute__((address_space(3))) float;
@@ -199,6 +203,9 @@ namespace vmv
         env_cptr dev;              // device memory, wave-uniform (scalar loads)
         lds_cptr lds;              // primitive block in LDS
         uint32_t capt0_planes_in_lds;  // how many leading split planes of point cloud 0 sit in LDS behind the block
+        lds_cptr radii;            // the robot's radius table (gen: kRadii) copied to LDS once per workgroup, for
+                                   // re-dealt items whose sphere index differs per lane (a __constant__ table read
+                                   // with a per-lane index is a global load on the critical path of every round)
     };
 
     // collision/math.hh:10-42
@@ -769,22 +776,22 @@ namespace vmv
     env_gate(const EnvView E_, lds_cptr slab, lds_ptr scratch_, const int radius_index_, const bool active)
     {
         const uint32_t lane = __lane_id();
-        const EnvView E{uniform(E_.dev), uniform(E_.lds), uniform(E_.capt0_planes_in_lds)};
+        const EnvView E{uniform(E_.dev), uniform(E_.lds), uniform(E_.capt0_planes_in_lds), uniform(E_.radii)};
         lds_u32 *list = (lds_u32 *) uniform((lds_cptr) scratch_);
         lds_u32 *mask_lane = list + 2 * kWave + 4 + lane;
         bool own;
         if (E.dev->masked_fine && E.dev->grid != nullptr)
-            own = env_hit_grid<G>(E, slab[0], slab[kWave], slab[2 * kWave], Tab::radius(uniform(radius_index_)), active,
+            own = env_hit_grid<G>(E, slab[0], slab[kRow], slab[2 * kRow], Tab::radius(uniform(radius_index_)), active,
                                   mask_lane);
         else if (E.dev->masked_fine)
         {
 #pragma unroll
             for (int w = 0; w < kMaskWords; ++w) mask_lane[w * kWave] = 0u;
-            own = env_hit<G, 1>(E, slab[0], slab[kWave], slab[2 * kWave], Tab::radius(uniform(radius_index_)), active,
+            own = env_hit<G, 1>(E, slab[0], slab[kRow], slab[2 * kRow], Tab::radius(uniform(radius_index_)), active,
                                 mask_lane);
         }
         else
-            own = env_hit<G, 0>(E, slab[0], slab[kWave], slab[2 * kWave], Tab::radius(uniform(radius_index_)), active,
+            own = env_hit<G, 0>(E, slab[0], slab[kRow], slab[2 * kRow], Tab::radius(uniform(radius_index_)), active,
                                 nullptr);
         const bool gate = group_any<G>(own);
         const uint64_t mask = __ballot(gate);
@@ -800,7 +807,7 @@ namespace vmv
     env_fine(const EnvView E_, lds_cptr slab, lds_ptr scratch_, const int n_fine_, const int radii_offset_)
     {
         const uint32_t lane = __lane_id();
-        const EnvView E{uniform(E_.dev), uniform(E_.lds), uniform(E_.capt0_planes_in_lds)};
+        const EnvView E{uniform(E_.dev), uniform(E_.lds), uniform(E_.capt0_planes_in_lds), uniform(E_.radii)};
         lds_u32 *list = (lds_u32 *) uniform((lds_cptr) scratch_);
         lds_u32 *flags = list + kWave;
         const int n_fine = uniform(n_fine_), radii_offset = uniform(radii_offset_);
@@ -819,13 +826,13 @@ namespace vmv
             s = act ? s : 0;
             const int j = act ? (i - s * k) : 0;
             const uint32_t src = list[j];
-            lds_cptr p = wave_slab + 3 * (s + 1) * kWave + src;
+            lds_cptr p = wave_slab + 3 * (s + 1) * kRow + src;
             bool hit;
             if (masked)
-                hit = env_hit<G, 2>(E, p[0], p[kWave], p[2 * kWave], Tab::radius(radii_offset + s), act,
+                hit = env_hit<G, 2>(E, p[0], p[kRow], p[2 * kRow], E.radii[radii_offset + s], act,
                                     list + 2 * kWave + 4 + src);
             else
-                hit = env_hit<G, 0>(E, p[0], p[kWave], p[2 * kWave], Tab::radius(radii_offset + s), act, nullptr);
+                hit = env_hit<G, 0>(E, p[0], p[kRow], p[2 * kRow], E.radii[radii_offset + s], act, nullptr);
             if (hit) flags[src] = 1u;
         }
         wave_lds_sync();
@@ -840,6 +847,20 @@ namespace vmv
         wave_lds_sync();
         return __popcll(mask);
     }
+
+    // Appends the lanes whose predicate holds to an LDS list as (lane | tag) entries; returns the new length.
+    // The caller issues wave_lds_sync() before reading the list.
+    __device__ __forceinline__ int deal_append(lds_u32 *list, const int n, const bool pred, const uint32_t tag)
+    {
+        const uint64_t mask = __ballot(pred);
+        const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t) (mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) mask, 0u));
+        if (pred) list[n + (int) below] = __lane_id() | tag;
+        return n + __popcll(mask);
+    }
+
+    // per-wave LDS scratch of the self-collision kernels: lane list [64], hit flags [64], pad [4], A-side candidate
+    // words [64], compacted items [8 * 64]
+    constexpr int kSelfScratchWords = 3 * kWave + 4 + 8 * kWave;
 
     __device__ __forceinline__ bool env_flag(lds_ptr scratch)
     {
