@@ -75,6 +75,12 @@ int vmv_env_add_cuboid(vmv_env *env, const float *params15);
 /* Environment.add_capsule — environment.cc:134-147.  8 floats: x1 y1 z1 | xv yv zv | r | rdv
  * (collision/shapes.hh:128-143).  Filed as z-aligned iff xv == 0 and yv == 0. */
 int vmv_env_add_capsule(vmv_env *env, const float *params8);
+/* make_heightfield(center, scaling, dimensions, data) + Environment.add_heightfield — collision/factory.hh:363-423,
+ * bindings/environment.cc:100,149-151, collision/shapes.hh:250-312.  data: host pointer, row-major [yd][xd] fp32;
+ * scale3 as given to make_heightfield (the shape stores the reciprocals).  At most 4 per environment. */
+int vmv_env_add_heightfield(vmv_env *env, const float *center3, const float *scale3, size_t xd, size_t yd,
+                            const float *data);
+int vmv_env_heightfield_count(const vmv_env *env, size_t *count);
 /* Environment.add_capt_pointcloud(points, r_min, r_max, r_point) -> build ns — environment.cc:152-163,
  * collision/capt.hh:296-369.  points: host pointer, [n][3] fp32. */
 int vmv_env_add_capt_pointcloud(vmv_env *env, const float *points_xyz, size_t n, float r_min, float r_max,

@@ -168,6 +168,14 @@ typedef struct
     float *px, *py, *pz; /* [n_vox][cap], +inf padded (mvt.hh:650) */
 } vo_mvt;
 
+/* collision/shapes.hh:250-312 (xs, ys, zs are the reciprocal scales, factory.hh:365-386) */
+typedef struct
+{
+    float x, y, z, xs, ys, zs;
+    size_t xd, yd, xd2, yd2;
+    float *data;
+} vo_heightfield;
+
 struct vo_env
 {
     vo_sphere *spheres;
@@ -184,6 +192,8 @@ struct vo_env
     size_t n_capts;
     vo_mvt *mvts;
     size_t n_mvts;
+    vo_heightfield *heightfields;
+    size_t n_heightfields;
 };
 
 vo_env *vo_env_create(void) { return (vo_env *) calloc(1, sizeof(vo_env)); }
@@ -222,6 +232,8 @@ void vo_env_destroy(vo_env *e)
     free(e->capts);
     for (size_t i = 0; i < e->n_mvts; ++i) mvt_free(&e->mvts[i]);
     free(e->mvts);
+    for (size_t i = 0; i < e->n_heightfields; ++i) free(e->heightfields[i].data);
+    free(e->heightfields);
     free(e);
 }
 
@@ -320,6 +332,19 @@ void vo_env_add_capsule(vo_env *e, const float *p)
         e->capsules[e->n_capsules++] = c;
         qsort(e->capsules, e->n_capsules, sizeof(vo_capsule), cmp_capsule);
     }
+}
+
+/* bindings/environment.cc:149-151 + factory.hh:365-386: scale -> reciprocal; no sorting, min_distance unused */
+int vo_env_add_heightfield(vo_env *e, const float center[3], const float scale[3], size_t xd, size_t yd, const float *data)
+{
+    if (!xd || !yd) return -1;
+    vo_heightfield h = {center[0], center[1], center[2], 1.F / scale[0], 1.F / scale[1], 1.F / scale[2],
+                        xd,        yd,        xd / 2,    yd / 2,         NULL};
+    h.data = (float *) malloc(xd * yd * sizeof(float));
+    memcpy(h.data, data, xd * yd * sizeof(float));
+    e->heightfields = (vo_heightfield *) realloc(e->heightfields, (e->n_heightfields + 1) * sizeof(vo_heightfield));
+    e->heightfields[e->n_heightfields++] = h;
+    return 0;
 }
 
 void vo_env_counts(const vo_env *e, size_t counts[6])
@@ -1001,6 +1026,24 @@ static inline float sphere_z_aligned_capsule(const vo_capsule *c, float x, float
     return sum - rs * rs;
 }
 
+/* collision/sphere_heightfield.hh:8-31, one lane.  The cell index is clamped to [0, xd] x [0, yd] by the reference, one
+ * past the image on both axes, so it can address up to xd + 1 floats beyond the data (an out-of-bounds gather, UB).
+ * Here such an index reads the last pixel; every in-bounds index is the reference's. */
+static inline float sphere_heightfield(const vo_heightfield *a, float x, float y, float z, float r)
+{
+    const float xo = a->x - x, yo = a->y - y;
+    const float xs = floorf(vclamp(a->xs * xo + (float) a->xd2, 0.F, (float) a->xd));
+    const float ys = floorf(vclamp(a->ys * yo + (float) a->yd2, 0.F, (float) a->yd));
+    const float index = ys * (float) a->xd + xs;
+    long idx = lrintf(index); /* _mm256_cvtps_epi32: round to nearest even (vector/avx.hh:629) */
+    const long last = (long) (a->xd * a->yd) - 1;
+    if (idx > last) idx = last;
+    if (idx < 0) idx = 0;
+    const float zh = a->data[idx];
+    const float zhs = a->zs * zh + a->z;
+    return z - r - zhs;
+}
+
 /* ------------------------------------------------------------------------- */
 /* sphere_environment_in_collision (collision/validity.hh:47-158) on a rake   */
 /* ------------------------------------------------------------------------- */
@@ -1033,7 +1076,10 @@ static int sphere_environment_in_collision(const vo_env *e, const float *sx, con
     LIST_LOOP(e->n_z_cuboids, e->z_cuboids[i].min_distance,
               sphere_z_aligned_cuboid(e->z_cuboids[i].p, sx[l], sy[l], sz[l], rsq))
 #undef LIST_LOOP
-    /* heightfields: out of scope */
+    /* validity.hh:131-137 */
+    for (size_t i = 0; i < e->n_heightfields; ++i)
+        for (int l = 0; l < lanes; ++l)
+            if (signbit_set(sphere_heightfield(&e->heightfields[i], sx[l], sy[l], sz[l], sr))) return 1;
     float radii[VO_RAKE];
     for (int l = 0; l < lanes; ++l) radii[l] = sr;
     for (size_t i = 0; i < e->n_capts; ++i)

@@ -44,6 +44,9 @@ void vo_env_add_sphere(vo_env *e, float x, float y, float z, float r);
 void vo_env_add_cuboid(vo_env *e, const float *p15);
 /* 8 floats: x1 y1 z1 | xv yv zv | r | rdv (collision/shapes.hh:128-143) */
 void vo_env_add_capsule(vo_env *e, const float *p8);
+/* make_heightfield + add_heightfield (collision/factory.hh:363-423, bindings/environment.cc:100,149-151): row-major
+ * data[yd][xd]; `scale` as given to make_heightfield (the shape stores the reciprocals).  Returns 0 on success. */
+int vo_env_add_heightfield(vo_env *e, const float center[3], const float scale[3], size_t xd, size_t yd, const float *data);
 /* collision/capt.hh:296-369; returns 0 on success */
 int vo_env_add_capt(vo_env *e, const float *points_xyz, size_t n, float r_min, float r_max, float r_point);
 

@@ -61,6 +61,19 @@ def spec_for(kind, robot="panda", seed=0):
         spec = shell_spec(seed + 5, 3, 3)
         spec.append(("mvt", (pts, r_min, r_max, lo, hi, POINT_RADIUS)))
         return spec
+    if kind == "heightfield":  # terrain under/around the robot + a few primitives (sphere_heightfield.hh)
+        rng = np.random.default_rng(seed + 13)
+        xd, yd = 48, 48
+        gx, gy = np.meshgrid(np.arange(xd), np.arange(yd))
+        rr = np.hypot(gx - xd / 2, gy - yd / 2) / (xd / 2)
+        img = 0.85 * rr ** 2 + 0.12 * np.sin(gx / 3.0) * np.cos(gy / 4.0) + 0.05 * rng.random((yd, xd))
+        img = np.clip(img, 0.0, 1.0).astype(np.float32)
+        # a bowl around the robot: the image spans 2.4 m x 2.4 m (scale = metres per pixel), floor under the robot's base, rim 1.4 m higher;
+        # small enough that lanes also run off the image on every side (the clamped border cells)
+        spec = shell_spec(seed + 5, 3, 3)
+        spec.append(("heightfield", (np.array([0.1, -0.05, {"panda": -0.3, "ur5": 0.1, "fetch": -0.42, "baxter": -1.38}[robot]], np.float32),
+                                     np.array([2.4 / xd, 2.4 / yd, 1.0 / 1.6], np.float32), xd, yd, img.reshape(-1))))
+        return spec
     raise KeyError(kind)
 
 
@@ -73,6 +86,8 @@ def build_oracle_env(o, spec):
             e.add_cuboid(p)
         elif kind == "capsule":
             e.add_capsule(p)
+        elif kind == "heightfield":
+            e.add_heightfield(*p)
         elif kind == "mvt":
             rc = e.add_mvt(*p)
             if rc != 0:

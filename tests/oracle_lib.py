@@ -61,6 +61,8 @@ class Oracle:
         L.vo_env_add_sphere.argtypes = [ctypes.c_void_p] + [ctypes.c_float] * 4
         L.vo_env_add_cuboid.argtypes = [ctypes.c_void_p, _fp]
         L.vo_env_add_capsule.argtypes = [ctypes.c_void_p, _fp]
+        L.vo_env_add_heightfield.argtypes = [ctypes.c_void_p, _fp, _fp, ctypes.c_size_t, ctypes.c_size_t, _fp]
+        L.vo_env_add_heightfield.restype = ctypes.c_int
         L.vo_env_add_capt.argtypes = [ctypes.c_void_p, _fp, ctypes.c_size_t] + [ctypes.c_float] * 3
         L.vo_env_add_capt.restype = ctypes.c_int
         L.vo_env_add_mvt.argtypes = [ctypes.c_void_p, _fp, ctypes.c_size_t, ctypes.c_float, ctypes.c_float, _fp, _fp,
@@ -199,6 +201,11 @@ class OracleEnv:
         p = np.ascontiguousarray(p15, np.float32)
         assert p.size == 15
         self.o.L.vo_env_add_cuboid(self.h, _f(p))
+
+    def add_heightfield(self, center, scale, xd, yd, data):
+        c, sc, d = (np.ascontiguousarray(a, np.float32) for a in (center, scale, data))
+        assert d.size == xd * yd
+        assert self.o.L.vo_env_add_heightfield(self.h, _f(c), _f(sc), xd, yd, _f(d.reshape(-1))) == 0
 
     def add_capsule(self, p8):
         p = np.ascontiguousarray(p8, np.float32)

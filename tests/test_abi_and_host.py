@@ -110,6 +110,38 @@ def test_shape_constructors(vamp):
     assert [len(t[k]) for k in ("spheres", "cuboids", "z_cuboids", "capsules", "z_capsules")] == [1, 1, 1, 1, 1]
 
 
+def test_heightfield_builder_and_oracle_semantics(vamp, oracle):
+    """make_heightfield stores reciprocal scales (factory.hh:376-386); the ABI takes the same arguments, keeps at most
+    four per environment, and the oracle's lookup follows sphere_heightfield.hh (flat terrain: a sphere collides iff
+    its bottom is below the terrain at its centre cell)."""
+    import ctypes
+
+    hf = vamp.make_heightfield([0.5, -0.5, 0.1], [0.05, 0.1, 2.0], (4, 3), np.arange(12, dtype=np.float32) / 12)
+    assert (hf.x, hf.y, hf.z) == (0.5, -0.5, np.float32(0.1)) and hf.xs == np.float32(1) / np.float32(0.05)
+    assert hf.zs == 0.5 and (hf.xd, hf.yd) == (4, 3)
+    e = vamp.Environment()
+    for _ in range(4):
+        e.add_heightfield(hf)
+    h = e._build(finalize=False)
+    n = ctypes.c_size_t(0)
+    assert vamp._lib.lib.vmv_env_heightfield_count(h, ctypes.byref(n)) == 0 and n.value == 4
+    vamp._lib.lib.vmv_env_destroy(h)
+    e.add_heightfield(hf)
+    with pytest.raises(vamp.VmvError) as ei:
+        e._build(finalize=False)
+    assert ei.value.status == 4  # VMV_ERR_CAPACITY
+    with pytest.raises(TypeError):
+        vamp.make_heightfield([0, 0, 0], [1, 1, 1], (4, 3), np.zeros(11, np.float32))
+    # oracle: flat terrain of height 0.3 (zs * 0.6 + z = 0.5 * 0.6 + 0.0), 1 m x 1 m
+    oe = oracle.env()
+    oe.add_heightfield([0, 0, 0], [0.1, 0.1, 2.0], 10, 10, np.full(100, 0.6, np.float32))
+    f = ctypes.POINTER(ctypes.c_float)
+    for c, r, want in (([0.1, 0.1, 0.5], 0.1, 0), ([0.1, 0.1, 0.35], 0.1, 1), ([5.0, -7.0, 0.39], 0.1, 1),
+                       ([5.0, -7.0, 0.41], 0.1, 0)):  # far outside the image: clamped border cell, same height
+        cc = np.array(c, np.float32)
+        assert oracle.L.vo_sphere_environment_in_collision(oe.h, cc.ctypes.data_as(f), ctypes.c_float(r)) == want
+
+
 def test_compute_fails_loudly_without_gpu(vamp):
     if vamp.device_count() > 0:
         pytest.skip("a GPU is present")

@@ -11,7 +11,7 @@ from test_oracle_pins import mt19937_uniform_configs
 
 pytestmark = pytest.mark.gpu
 ROBOTS = ["panda", "ur5", "fetch", "baxter"]
-KINDS = ["empty", "cage", "shell64", "mixed", "capt"]
+KINDS = ["empty", "cage", "shell64", "mixed", "capt", "heightfield"]
 
 
 def uniform_configs(oracle, name, n, seed):
@@ -40,7 +40,7 @@ def test_validate_batch_bit_exact(vamp, oracle, name, kind):
 
 
 @pytest.mark.parametrize("name", ROBOTS)
-@pytest.mark.parametrize("kind", ["empty", "shell64", "mixed", "capt"])
+@pytest.mark.parametrize("kind", ["empty", "shell64", "mixed", "capt", "heightfield"])
 def test_validate_motion_batch_bit_exact(vamp, oracle, name, kind):
     """Edges with distinct configurations per rake lane: exercises the 8-lane "any lane" gating."""
     env, oenv = make_env(kind, oracle, name)

@@ -21,7 +21,7 @@ import numpy as np
 from . import _lib
 from ._lib import VmvError, check, lib
 
-__all__ = ["Sphere", "Cuboid", "Cylinder", "Environment", "robots", "device_count", "set_device", "abi_version",
+__all__ = ["Sphere", "Cuboid", "Cylinder", "HeightField", "make_heightfield", "png_to_heightfield", "Environment", "robots", "device_count", "set_device", "abi_version",
            "VmvError", "unpack_bits", "POINT_RADIUS"]
 
 POINT_RADIUS = 0.0025  # reference src/vamp/constants.py:25
@@ -125,6 +125,38 @@ class Cuboid:
     z = property(lambda s: float(s.params[2]))
 
 
+class HeightField:
+    """vamp.HeightField (bindings/environment.cc:102-109, collision/shapes.hh:250-312): flattened `data` with
+    xd = dimensions[0] used as the row length of the lookup (index = ys * xd + xs, sphere_heightfield.hh:22), exactly
+    as the reference does.  xs, ys, zs are the reciprocal scales (collision/factory.hh:376-386)."""
+
+    def __init__(self, center, scaling, dimensions, data):
+        self.center = _f32(center).reshape(3).copy()
+        self.scaling = _f32(scaling).reshape(3).copy()
+        self.xd, self.yd = int(dimensions[0]), int(dimensions[1])
+        self.data = _f32(data).reshape(-1).copy()
+        if self.data.size != self.xd * self.yd:
+            raise TypeError("data must hold dimensions[0] * dimensions[1] values")
+        self.x, self.y, self.z = (float(v) for v in self.center)
+        one = np.float32(1.0)
+        self.xs, self.ys, self.zs = (float(one / v) for v in self.scaling)
+
+
+def make_heightfield(center, scaling, dimensions, data) -> HeightField:
+    """vamp.make_heightfield (bindings/environment.cc:100)."""
+    return HeightField(center, scaling, dimensions, data)
+
+
+def png_to_heightfield(filename, center, scaling) -> HeightField:
+    """vamp.png_to_heightfield (reference src/vamp/__init__.py:54-66): grey-scale image / 255, flipped vertically;
+    dimensions = array.shape, as the reference passes them."""
+    from PIL import Image  # same optional dependency as the reference
+
+    array = np.asarray(Image.open(filename).convert("L")) * 1 / 255.0
+    array = np.flip(array, axis=0)
+    return make_heightfield(center, scaling, array.shape, list(array.flatten()))
+
+
 class Cylinder:
     """vamp.Cylinder(center, euler_xyz, radius, length) | Cylinder(endpoint1, endpoint2, radius)
     — collision/factory.hh:104-223; the environment treats it as a capsule (environment.cc:134-147)."""
@@ -186,6 +218,10 @@ class Environment:
         self._ops.append(("capsule", capsule.params.copy()))
         self._dirty()
 
+    def add_heightfield(self, heightfield: HeightField):
+        self._ops.append(("heightfield", heightfield))
+        self._dirty()
+
     def add_capt_pointcloud(self, points, r_min, r_max, r_point):
         """-> CAPT build time in nanoseconds (environment.cc:152-163)."""
         pts = _f32(points)
@@ -241,6 +277,9 @@ class Environment:
                     check(lib.vmv_env_add_cuboid(h, _fp(arg)), "vmv_env_add_cuboid")
                 elif kind == "capsule":
                     check(lib.vmv_env_add_capsule(h, _fp(arg)), "vmv_env_add_capsule")
+                elif kind == "heightfield":
+                    check(lib.vmv_env_add_heightfield(h, _fp(arg.center), _fp(arg.scaling), arg.xd, arg.yd, _fp(arg.data)),
+                          "vmv_env_add_heightfield")
                 elif kind == "mvt":
                     pts, r_min, r_max, lo, hi, r_point = arg
                     check(lib.vmv_env_add_mvt_pointcloud(h, _fp(pts), pts.shape[0], r_min, r_max, _fp(lo), _fp(hi),

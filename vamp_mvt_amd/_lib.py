@@ -75,6 +75,8 @@ def _load():
         "vmv_env_add_sphere": (I, [V, F, F, F, F]),
         "vmv_env_add_cuboid": (I, [V, c_float_p]),
         "vmv_env_add_capsule": (I, [V, c_float_p]),
+        "vmv_env_add_heightfield": (I, [V, c_float_p, c_float_p, S, S, c_float_p]),
+        "vmv_env_heightfield_count": (I, [V, c_size_p]),
         "vmv_env_add_capt_pointcloud": (I, [V, c_float_p, S, F, F, F, c_u64_p]),
         "vmv_env_add_mvt_pointcloud": (I, [V, c_float_p, S, F, F, c_float_p, c_float_p, F, c_u64_p, ctypes.POINTER(I)]),
         "vmv_env_mvt_count": (I, [V, c_size_p]),

@@ -136,6 +136,13 @@ struct vmv_env
     std::vector<Cuboid> cuboids, z_cuboids;
     std::vector<vmv::CaptArrays> capts;
     std::vector<vmv::MvtArrays> mvts;
+    struct HeightField
+    {
+        float c[3], inv[3];
+        size_t xd, yd;
+        std::vector<float> data;
+    };
+    std::vector<HeightField> heightfields;
 
     bool finalized = false;
     int device = -1;
@@ -324,6 +331,30 @@ extern "C"
         ((p[3] == 0.0f && p[4] == 0.0f) ? env->z_capsules : env->capsules).push_back(c);  // environment.cc:137-144
         return VMV_OK;
     }
+    int vmv_env_add_heightfield(vmv_env *env, const float *center, const float *scale, size_t xd, size_t yd,
+                                const float *data)
+    {
+        VMV_MUTABLE(env)
+        if (!center || !scale || !data || xd == 0 || yd == 0 || xd * yd > (size_t) 1 << 30) return VMV_ERR_INVALID_ARGUMENT;
+        if (env->heightfields.size() >= (size_t) vmv::kMaxHeightFields) return VMV_ERR_CAPACITY;
+        vmv_env::HeightField h;
+        for (int k = 0; k < 3; ++k)
+        {
+            h.c[k] = center[k];
+            h.inv[k] = 1.F / scale[k];  // factory.hh:376-386
+        }
+        h.xd = xd;
+        h.yd = yd;
+        h.data.assign(data, data + xd * yd);
+        env->heightfields.push_back(std::move(h));
+        return VMV_OK;
+    }
+    int vmv_env_heightfield_count(const vmv_env *env, size_t *count)
+    {
+        if (!env || !count) return VMV_ERR_INVALID_ARGUMENT;
+        *count = env->heightfields.size();
+        return VMV_OK;
+    }
     int vmv_env_add_capt_pointcloud(vmv_env *env, const float *pts, size_t n, float r_min, float r_max, float r_point,
                                     uint64_t *build_ns)
     {
@@ -498,6 +529,18 @@ extern "C"
             d.inv_scale = m.inv_scale;
             d.r_point = m.r_point;
             d.grid_width = m.grid_width;
+        }
+        D.n_heightfield = (uint32_t) env->heightfields.size();
+        for (size_t i = 0; i < env->heightfields.size(); ++i)
+        {
+            const vmv_env::HeightField &h = env->heightfields[i];
+            vmv::HeightFieldDev &d = D.heightfield[i];
+            if ((rc = upload(env, h.data, &d.data)) != VMV_OK) return rc;
+            d.x = h.c[0], d.y = h.c[1], d.z = h.c[2];
+            d.xs = h.inv[0], d.ys = h.inv[1], d.zs = h.inv[2];
+            d.xd = (float) h.xd, d.yd = (float) h.yd;
+            d.xd2 = (float) (h.xd / 2), d.yd2 = (float) (h.yd / 2);  // shapes.hh:289-290
+            d.last = (uint32_t) (h.xd * h.yd - 1);
         }
         // broad-phase grid of the gate pass, one per robot (its reach is the robot's largest bounding radius)
         std::vector<vmv::GridPrim> gp;

@@ -170,6 +170,15 @@ namespace vmv
     };
     constexpr int kMaxMvt = 4;
 
+    struct HeightFieldDev  // collision/shapes.hh:250-312
+    {
+        const float *data;  // row-major [yd][xd]
+        float x, y, z, xs, ys, zs;
+        float xd, yd, xd2, yd2;  // image size and half size, as the floats the reference converts them to
+        uint32_t last;           // xd * yd - 1
+    };
+    constexpr int kMaxHeightFields = 4;
+
     struct EnvDev  // kernel argument (by value)
     {
         const float *prims;  // HBM image of the LDS primitive block
@@ -189,6 +198,8 @@ namespace vmv
         uint32_t n_mvt;
         CaptDev capt[kMaxCapt];
         MvtDev mvt[kMaxMvt];
+        uint32_t n_heightfield;
+        HeightFieldDev heightfield[kMaxHeightFields];
     };
 
     // explicit address spaces for everything that crosses a non-inlined call: the constant space makes the
@@ -613,6 +624,24 @@ namespace vmv
         }
     }
 
+    // sphere_heightfield (collision/sphere_heightfield.hh:8-31), per lane; true = collides.  The reference clamps the
+    // cell index to [0, xd] x [0, yd], one past the image on both axes, and gathers up to xd + 1 floats beyond the data
+    // (undefined behaviour); here such an index reads the last pixel.  Every in-bounds index is the reference's.
+    __device__ __forceinline__ bool heightfield_collides(const env_cptr Dp, const uint32_t hi, float x, float y, float z, float r)
+    {
+        const HeightFieldDev __attribute__((address_space(4))) *a = &Dp->heightfield[hi];
+        const float xo = a->x - x, yo = a->y - y;
+        const float xs = floorf(vclamp(a->xs * xo + a->xd2, 0.F, a->xd));
+        const float ys = floorf(vclamp(a->ys * yo + a->yd2, 0.F, a->yd));
+        const float index = ys * a->xd + xs;
+        int idx = (int) rintf(index);  // _mm256_cvtps_epi32 (vector/avx.hh:629)
+        idx = idx < 0 ? 0 : idx;
+        const uint32_t u = (uint32_t) idx > a->last ? a->last : (uint32_t) idx;
+        const float zh = a->data[u];
+        const float zhs = a->zs * zh + a->z;
+        return neg(z - r - zhs);
+    }
+
     // sphere_environment_in_collision (collision/validity.hh:47-158) for one robot sphere, per lane.
     //  * returns this lane's own "hits something" flag; the caller folds it over the rake with group_any.
     //  * the sorted early-break is rake-wide in the reference (all 8 lanes must agree).  Lists are sorted
@@ -656,6 +685,11 @@ namespace vmv
                                          ext, ext_wave, hit, mask);
         }
         hit = hit && active;
+        for (uint32_t hi = 0; hi < D.n_heightfield; ++hi)  // validity.hh:131-137
+        {
+            if (!wave_any(active && !hit)) break;
+            hit |= active && heightfield_collides(Dp, hi, x, y, z, r);
+        }
         for (uint32_t ci = 0; ci < D.n_capt; ++ci)
         {
             const bool act = active && !hit;
@@ -729,6 +763,11 @@ namespace vmv
         list_grid<kCuboid>(E, D.n_cuboid, D.off_cuboid, D.wbase_cuboid, cell, x, y, z, r, rsq, ext, inside, hit, mask_lane);
         list_grid<kZCuboid>(E, D.n_zcuboid, D.off_zcuboid, D.wbase_zcuboid, cell, x, y, z, r, rsq, ext, inside, hit, mask_lane);
         hit = hit && active;
+        for (uint32_t hi = 0; hi < D.n_heightfield; ++hi)  // validity.hh:131-137
+        {
+            if (!wave_any(active && !hit)) break;
+            hit |= active && heightfield_collides(Dp, hi, x, y, z, r);
+        }
         for (uint32_t ci = 0; ci < D.n_capt; ++ci)
         {
             const bool act = active && !hit;

@@ -78,6 +78,9 @@ def environment_from_spec(spec):
             e.add_capsule(vamp.Cylinder.from_canonical(p))
         elif kind == "mvt":
             e.add_mvt_pointcloud(*p)
+        elif kind == "heightfield":
+            center, scale, xd, yd, data = p
+            e.add_heightfield(vamp.make_heightfield(center, scale, (xd, yd), data))
         else:
             e.add_capt_pointcloud(*p)
     return e
