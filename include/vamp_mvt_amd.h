@@ -62,6 +62,17 @@ int vmv_robot_bounds(int robot, float *lower, float *span, float *descale);
 const char *vmv_robot_joint_name(int robot, int joint);
 const char *vmv_robot_end_effector(int robot);
 
+/* ---- point-cloud filters (replaces vamp.filter_pointcloud, bindings/environment.cc:183-239) ------------ */
+/* filter_type 0 = "scdf" (collision/filter.hh:175-275; uses min_dist, max_range, cull), 1 = "centervox"
+ * (collision/filter_centervox.hh:288-313; uses voxel_size, max_range).  points / out: host pointers, [n][3] fp32; the
+ * kept points come back in the reference's order.  out may be NULL (count only); VMV_ERR_CAPACITY if out is too small
+ * or where the reference throws "Voxel pool exhausted".  nanoseconds: wall time including transfers (what the
+ * reference's binding reports), device_nanoseconds: HIP-event time of the device work alone; both may be NULL. */
+int vmv_filter_pointcloud(const float *points_xyz, size_t n, float min_dist, float max_range, float voxel_size,
+                          const float *origin3, const float *workspace_min3, const float *workspace_max3, int cull,
+                          int filter_type, float *out_xyz, size_t capacity, size_t *n_out, uint64_t *nanoseconds,
+                          uint64_t *device_nanoseconds);
+
 /* ---- environment (replaces vamp.Environment, bindings/environment.cc:111-163) -------------------------- */
 typedef struct vmv_env vmv_env;
 

@@ -1330,3 +1330,221 @@ void vo_validate_batch_mt(int robot, const vo_env *e, const float *q, size_t n, 
     }
     for (int t = 0; t < started; ++t) pthread_join(tid[t], NULL);
 }
+
+/* ------------------------------------------------------------------------- */
+/* point-cloud filters (collision/filter.hh, collision/filter_centervox.hh)   */
+/* ------------------------------------------------------------------------- */
+
+/* float -> uint32_t as x86-64 compilers emit it for `return <float expr>;` in a function returning uint32_t
+ * (filter.hh:129-132): cvttss2si to 64 bits, low 32 bits kept; NaN / out of range give the "integer indefinite"
+ * 0x8000000000000000, i.e. 0.  (The C++ conversion is undefined for negative values; this is what the reference's
+ * build does with them, and culled copies of point 0 do reach it - see vo_filter_scdf.) */
+static uint32_t cvt_f32_u32_x86(float v)
+{
+    if (!(v > -9223372036854775808.0f && v < 9223372036854775808.0f)) return 0u;
+    return (uint32_t) (uint64_t) (int64_t) v;
+}
+/* filter.hh:129-132 */
+static uint32_t remap_point(float x, float mn, float mx) { return cvt_f32_u32_x86(((x - mn) / (mx - mn)) * 1000.0f); }
+/* _pdep_u32 */
+static uint32_t pdep32(uint32_t src, uint32_t mask)
+{
+    uint32_t out = 0;
+    for (uint32_t bit = 1; mask; bit <<= 1)
+    {
+        const uint32_t low = mask & (0u - mask);
+        if (src & bit) out |= low;
+        mask &= mask - 1;
+    }
+    return out;
+}
+/* filter.hh:149-152 */
+static uint32_t morton_pdep(uint32_t x, uint32_t y, uint32_t z)
+{
+    return pdep32(x, 0x49249249u) | pdep32(y, 0x92492492u) | pdep32(z, 0x24924924u);
+}
+
+typedef struct
+{
+    uint32_t first, second, pos;
+} vo_morton;
+static int cmp_morton(const void *a, const void *b)
+{
+    const vo_morton *x = (const vo_morton *) a, *y = (const vo_morton *) b;
+    if (x->second != y->second) return x->second < y->second ? -1 : 1;
+    return x->pos < y->pos ? -1 : (x->pos > y->pos); /* ties: current order (the reference's pdqsort leaves it open) */
+}
+
+/* filter_pointcloud (collision/filter.hh:175-275), "scdf".  out_xyz: capacity n points; returns the number kept.
+ * Restated quirks: `max` is the MIN of origin + range (:193); the index vector is resized to n before culling, so the
+ * n - hi entries behind the survivors all refer to point 0 (:195-216) and take part in every later step; min/max of
+ * the next curve are averaged with the extremes over all three coordinates (:232-233, :261-262). */
+size_t vo_filter_scdf(const float *pc, size_t n, float min_dist, float max_range, const float origin[3],
+                      const float ws_min[3], const float ws_max[3], int cull, float *out_xyz)
+{
+    if (n == 0) return 0;
+    const float sqdist = min_dist * min_dist, sqrange = max_range * max_range;
+    float mn = fminf(fminf(origin[0] - max_range, origin[1] - max_range), origin[2] - max_range);
+    float mx = fminf(fminf(origin[0] + max_range, origin[1] + max_range), origin[2] + max_range);
+    vo_morton *m = (vo_morton *) calloc(n, sizeof(vo_morton));
+    vo_morton *f = (vo_morton *) calloc(n, sizeof(vo_morton));
+    size_t size = n, hi = 0;
+    for (size_t i = 0; i < n; ++i)
+    {
+        const float *p = pc + 3 * i;
+        if (!cull || (sql2_3(p[0], p[1], p[2], origin[0], origin[1], origin[2]) < sqrange && ws_min[0] <= p[0] &&
+                      p[0] <= ws_max[0] && ws_min[1] <= p[1] && p[1] <= ws_max[1] && ws_min[2] <= p[2] && p[2] <= ws_max[2]))
+            m[hi++].first = (uint32_t) i;
+    }
+    static const int perms[6][3] = {{0, 1, 2}, {0, 2, 1}, {1, 0, 2}, {1, 2, 0}, {2, 0, 1}, {2, 1, 0}};
+    for (int it = 0; it < 6; ++it)
+    {
+        const int *c = perms[it];
+        float new_min = mx, new_max = mn;
+        for (size_t i = 0; i < size; ++i)
+        {
+            const float *p = pc + 3 * (size_t) m[i].first;
+            const uint32_t c0 = remap_point(p[c[0]], mn, mx), c1 = remap_point(p[c[1]], mn, mx),
+                           c2 = remap_point(p[c[2]], mn, mx);
+            new_min = fminf(fminf(fminf(new_min, p[0]), p[1]), p[2]);
+            new_max = fmaxf(fmaxf(fmaxf(new_max, p[0]), p[1]), p[2]);
+            m[i].second = morton_pdep(c0, c1, c2);
+            m[i].pos = (uint32_t) i;
+        }
+        qsort(m, size, sizeof(vo_morton), cmp_morton);
+        size_t k = 0;
+        f[k++] = m[0];
+        for (size_t i = 1; i < size; ++i)
+        {
+            const float *p1 = pc + 3 * (size_t) m[i].first, *p2 = pc + 3 * (size_t) f[k - 1].first;
+            if (sql2_3(p1[0], p1[1], p1[2], p2[0], p2[1], p2[2]) > sqdist) f[k++] = m[i];
+        }
+        vo_morton *t = m;
+        m = f;
+        f = t;
+        size = k;
+        mx = (float) ((double) (new_max + mx) / 2.);
+        mn = (float) ((double) (new_min + mn) / 2.);
+    }
+    for (size_t i = 0; i < size; ++i) memcpy(out_xyz + 3 * i, pc + 3 * (size_t) m[i].first, 3 * sizeof(float));
+    free(m);
+    free(f);
+    return size;
+}
+
+/* filter_pointcloud_centervox (collision/filter_centervox.hh:16-313).  Returns the number kept, or (size_t) -1 where
+ * the reference throws "Voxel pool exhausted" (:132-134).  Output order = the reference's extract_points(): x tables,
+ * y tables and voxels each in order of first appearance (:150-166). */
+size_t vo_filter_centervox(const float *pc, size_t n, float voxel_size, float max_range, const float origin[3],
+                           const float ws_min[3], const float ws_max[3], float *out_xyz)
+{
+    if (n == 0) return 0;
+    const float max_range_sq = max_range * max_range;
+    const float width = fmaxf(fmaxf(ws_max[0] - ws_min[0], ws_max[1] - ws_min[1]), ws_max[2] - ws_min[2]);
+    int grid_width = (int) ceilf(width / voxel_size);
+    if (grid_width > 255) grid_width = 255;
+    const float isf = (float) grid_width / width;
+    const float per_dim = width / voxel_size;
+    size_t pool = (size_t) (powf(per_dim, 3.0f) * 0.05f);
+    if (pool > 32768) pool = 32768;
+    typedef struct
+    {
+        float stored[3], center[3], dsq;
+    } voxel;
+    voxel *vox = (voxel *) malloc((pool ? pool : 1) * sizeof(voxel));
+    size_t n_vox = 0;
+    /* x -> y-table, (y-table, y) -> z-table, (z-table, z) -> voxel; tables in creation order */
+    int x_to_y[255];
+    for (int i = 0; i < 255; ++i) x_to_y[i] = -1;
+    size_t n_y = 0, n_z = 0, cap_z = 64;
+    int(*y_to_z)[255] = (int(*)[255]) malloc(255 * sizeof(*y_to_z));
+    size_t *y_first_z = NULL; /* z tables are listed per y table: keep (owner, order) */
+    (void) y_first_z;
+    int(*z_to_v)[255] = (int(*)[255]) malloc(cap_z * sizeof(*z_to_v));
+    int *z_owner = (int *) malloc(cap_z * sizeof(int));
+    size_t *z_count = (size_t *) malloc(cap_z * sizeof(size_t));
+    int(*z_list)[255] = (int(*)[255]) malloc(cap_z * sizeof(*z_list)); /* voxels of a z table in creation order */
+    int failed = 0;
+    for (size_t i = 0; i < n && !failed; ++i)
+    {
+        const float *p = pc + 3 * i;
+        const float dx = p[0] - origin[0], dy = p[1] - origin[1], dz = p[2] - origin[2];
+        if (dx * dx + dy * dy + dz * dz >= max_range_sq) continue;
+        if (p[0] < ws_min[0] || p[0] > ws_max[0] || p[1] < ws_min[1] || p[1] > ws_max[1] || p[2] < ws_min[2] ||
+            p[2] > ws_max[2])
+            continue;
+        int v[3];
+        for (int k = 0; k < 3; ++k)
+        {
+            int c = (int) ((p[k] - ws_min[k]) * isf);
+            v[k] = c < 0 ? 0 : (c > 254 ? 254 : c);
+        }
+        if (x_to_y[v[0]] < 0)
+        {
+            x_to_y[v[0]] = (int) n_y;
+            for (int j = 0; j < 255; ++j) y_to_z[n_y][j] = -1;
+            ++n_y;
+        }
+        const int yt = x_to_y[v[0]];
+        if (y_to_z[yt][v[1]] < 0)
+        {
+            if (n_z == cap_z)
+            {
+                cap_z *= 2;
+                z_to_v = (int(*)[255]) realloc(z_to_v, cap_z * sizeof(*z_to_v));
+                z_owner = (int *) realloc(z_owner, cap_z * sizeof(int));
+                z_count = (size_t *) realloc(z_count, cap_z * sizeof(size_t));
+                z_list = (int(*)[255]) realloc(z_list, cap_z * sizeof(*z_list));
+            }
+            y_to_z[yt][v[1]] = (int) n_z;
+            for (int j = 0; j < 255; ++j) z_to_v[n_z][j] = -1;
+            z_owner[n_z] = yt;
+            z_count[n_z] = 0;
+            ++n_z;
+        }
+        const int zt = y_to_z[yt][v[1]];
+        if (z_to_v[zt][v[2]] < 0)
+        {
+            if (n_vox >= pool)
+            {
+                failed = 1;
+                break;
+            }
+            voxel *nv = &vox[n_vox];
+            for (int k = 0; k < 3; ++k) nv->center[k] = ws_min[k] + ((float) v[k] + 0.5f) * voxel_size;
+            nv->dsq = -1.0f; /* unoccupied */
+            z_to_v[zt][v[2]] = (int) n_vox;
+            z_list[zt][z_count[zt]++] = (int) n_vox;
+            ++n_vox;
+        }
+        voxel *vx = &vox[z_to_v[zt][v[2]]];
+        const float ex = p[0] - vx->center[0], ey = p[1] - vx->center[1], ez = p[2] - vx->center[2];
+        const float nd = ex * ex + ey * ey + ez * ez;
+        if (vx->dsq < 0.0f || nd < vx->dsq)
+        {
+            memcpy(vx->stored, p, sizeof(vx->stored));
+            vx->dsq = nd;
+        }
+    }
+    size_t out = 0;
+    if (!failed)
+    {
+        /* y tables in creation order; within each, its z tables in creation order (they were appended to the owner's
+         * vector in that order: global creation order filtered by owner) */
+        for (size_t y = 0; y < n_y; ++y)
+            for (size_t z = 0; z < n_z; ++z)
+                if (z_owner[z] == (int) y)
+                    for (size_t i = 0; i < z_count[z]; ++i)
+                    {
+                        memcpy(out_xyz + 3 * out, vox[z_list[z][i]].stored, 3 * sizeof(float));
+                        ++out;
+                    }
+    }
+    free(vox);
+    free(y_to_z);
+    free(z_to_v);
+    free(z_owner);
+    free(z_count);
+    free(z_list);
+    return failed ? (size_t) -1 : out;
+}

@@ -99,6 +99,14 @@ int vo_capt_collides_simd(const vo_env *e, size_t index, const float *cx, const 
 /* sphere_environment_in_collision (collision/validity.hh:47-158) for one sphere (a rake of one lane); 1 = collides */
 int vo_sphere_environment_in_collision(const vo_env *e, const float c[3], float r);
 
+/* filter_pointcloud(pc, min_dist, max_range, origin, workspace_min, workspace_max, cull) — collision/filter.hh:175-275
+ * ("scdf", the space-filling-curve filter); out_xyz has room for n points; returns how many were kept. */
+size_t vo_filter_scdf(const float *pc, size_t n, float min_dist, float max_range, const float origin[3],
+                      const float ws_min[3], const float ws_max[3], int cull, float *out_xyz);
+/* filter_pointcloud_centervox — collision/filter_centervox.hh:16-313; (size_t) -1 where the reference throws */
+size_t vo_filter_centervox(const float *pc, size_t n, float voxel_size, float max_range, const float origin[3],
+                           const float ws_min[3], const float ws_max[3], float *out_xyz);
+
 /* robots */
 int vo_robot_id(const char *name); /* -1 if unknown */
 size_t vo_robot_dimension(int robot);

@@ -82,6 +82,10 @@ class Oracle:
         L.vo_capt_collides.argtypes = [ctypes.c_void_p, ctypes.c_size_t, _fp, ctypes.c_float]
         L.vo_capt_collides_simd.argtypes = [ctypes.c_void_p, ctypes.c_size_t, _fp, _fp, _fp, _fp, ctypes.c_int]
         L.vo_sphere_environment_in_collision.argtypes = [ctypes.c_void_p, _fp, ctypes.c_float]
+        for fn in ("vo_filter_scdf", "vo_filter_centervox"):
+            getattr(L, fn).restype = ctypes.c_size_t
+        L.vo_filter_scdf.argtypes = [_fp, ctypes.c_size_t, ctypes.c_float, ctypes.c_float, _fp, _fp, _fp, ctypes.c_int, _fp]
+        L.vo_filter_centervox.argtypes = [_fp, ctypes.c_size_t, ctypes.c_float, ctypes.c_float, _fp, _fp, _fp, _fp]
         L.vo_robot_id.argtypes = [ctypes.c_char_p]
         for fn in ("vo_robot_dimension", "vo_robot_n_spheres", "vo_robot_n_total_spheres", "vo_robot_resolution"):
             getattr(L, fn).argtypes = [ctypes.c_int]
@@ -100,6 +104,22 @@ class Oracle:
         L.vo_validate_batch.argtypes = [ctypes.c_int, ctypes.c_void_p, _fp, ctypes.c_size_t, _u8p]
         L.vo_validate_motion_batch.argtypes = [ctypes.c_int, ctypes.c_void_p, _fp, _fp, ctypes.c_size_t, _u8p]
         L.vo_validate_batch_mt.argtypes = [ctypes.c_int, ctypes.c_void_p, _fp, ctypes.c_size_t, _u8p, ctypes.c_int]
+
+    # -- point-cloud filters ---------------------------------------------------
+    def filter_scdf(self, pc, min_dist, max_range, origin, lo, hi, cull):
+        pc = np.ascontiguousarray(pc, np.float32).reshape(-1, 3)
+        out = np.zeros((max(len(pc), 1), 3), np.float32)
+        o, l, h = (np.ascontiguousarray(a, np.float32) for a in (origin, lo, hi))
+        m = self.L.vo_filter_scdf(_f(pc), len(pc), min_dist, max_range, _f(o), _f(l), _f(h), int(cull), _f(out))
+        return out[:m].copy()
+
+    def filter_centervox(self, pc, voxel_size, max_range, origin, lo, hi):
+        """-> points, or None where the reference throws (voxel pool exhausted)"""
+        pc = np.ascontiguousarray(pc, np.float32).reshape(-1, 3)
+        out = np.zeros((max(len(pc), 1), 3), np.float32)
+        o, l, h = (np.ascontiguousarray(a, np.float32) for a in (origin, lo, hi))
+        m = self.L.vo_filter_centervox(_f(pc), len(pc), voxel_size, max_range, _f(o), _f(l), _f(h), _f(out))
+        return None if m == ctypes.c_size_t(-1).value else out[:m].copy()
 
     # -- robots -------------------------------------------------------------
     def robot(self, name):

@@ -1,0 +1,164 @@
+"""Point-cloud filters: vamp.filter_pointcloud with filter_type "scdf" (collision/filter.hh:175-275)
+and "centervox" (collision/filter_centervox.hh).
+
+Oracle = oracle/vamp_oracle.c (vo_filter_scdf / vo_filter_centervox).  Parity unpinned against the reference itself:
+it cannot be built here (pdqsort, nanobind) and ships no filter fixtures; the restatement follows the source text, with
+equal Morton codes kept in their current order (the reference's pdqsort leaves that order open).  CPU tests pin the
+oracle against an independent slow Python restatement and against the filters' defining properties; the GPU tests
+compare the HIP implementation with the oracle point for point, in order."""
+import numpy as np
+import pytest
+
+ORIGIN = np.array([0.0, 0.0, 0.333], np.float32)  # Panda first joint (reference src/vamp/constants.py)
+RANGE = np.float32(1.19)
+LO, HI = ORIGIN - RANGE, ORIGIN + RANGE
+
+
+def scene_cloud(n, seed, spread=1.6):
+    """points on a few boxes / a cylinder around the robot plus outliers beyond the cull range (and a culled point 0)"""
+    rng = np.random.default_rng(seed)
+    parts = []
+    for _ in range(5):
+        c = rng.uniform(-0.9, 0.9, 3) + [0, 0, 0.4]
+        half = rng.uniform(0.05, 0.3, 3)
+        p = rng.uniform(-1, 1, (n // 6, 3)) * half
+        face = rng.integers(0, 3, len(p))
+        p[np.arange(len(p)), face] = np.sign(p[np.arange(len(p)), face]) * half[face]
+        parts.append(c + p)
+    a = rng.uniform(0, 2 * np.pi, n - 5 * (n // 6))
+    parts.append(np.stack([0.5 + 0.1 * np.cos(a), -0.4 + 0.1 * np.sin(a), rng.uniform(0, 0.8, len(a))], 1))
+    pc = np.concatenate(parts).astype(np.float32)
+    rng.shuffle(pc)
+    pc[::97] *= np.float32(spread)  # some points outside the range / workspace
+    pc[0] = [3.0, -2.5, 0.1]        # point 0 is culled: exercises the reference's tail entries (filter.hh:195-216)
+    return pc
+
+
+def slow_scdf(pc, min_dist, max_range, origin, lo, hi, cull):
+    """independent restatement of filter.hh:175-275 in numpy/Python (fp32 arithmetic, stable sort), small n only"""
+    f = np.float32
+    n = len(pc)
+    sqdist, sqrange = f(min_dist) * f(min_dist), f(max_range) * f(max_range)
+    mn = min(f(origin[k]) - f(max_range) for k in range(3))
+    mx = min(f(origin[k]) + f(max_range) for k in range(3))
+    first = []
+    for i in range(n):
+        d = pc[i] - origin
+        sq = f(f(f(d[0] * d[0]) + f(d[1] * d[1])) + f(d[2] * d[2]))
+        if not cull or (sq < sqrange and all(lo[k] <= pc[i, k] <= hi[k] for k in range(3))):
+            first.append(i)
+    first += [0] * (n - len(first))
+
+    def remap(x):
+        v = f(f(f(x - mn) / f(mx - mn)) * f(1000.0))
+        return int(np.int64(np.trunc(v))) & 0xffffffff if np.isfinite(v) and abs(v) < 2.0 ** 63 else 0
+
+    def pdep(src, mask):
+        out, bit = 0, 0
+        for pos in range(32):
+            if (mask >> pos) & 1:
+                out |= ((src >> bit) & 1) << pos
+                bit += 1
+        return out
+
+    for perm in ((0, 1, 2), (0, 2, 1), (1, 0, 2), (1, 2, 0), (2, 0, 1), (2, 1, 0)):
+        pts = pc[first]
+        new_min, new_max = min(mx, f(pts.min())), max(mn, f(pts.max()))
+        codes = [pdep(remap(p[perm[0]]), 0x49249249) | pdep(remap(p[perm[1]]), 0x92492492) |
+                 pdep(remap(p[perm[2]]), 0x24924924) for p in pts]
+        order = np.argsort(np.array(codes, np.uint64), kind="stable")
+        first = [first[j] for j in order]
+        kept = [first[0]]
+        for i in first[1:]:
+            d = pc[i] - pc[kept[-1]]
+            if f(f(f(d[0] * d[0]) + f(d[1] * d[1])) + f(d[2] * d[2])) > sqdist:
+                kept.append(i)
+        first = kept
+        mx = f((np.float64(f(new_max + mx))) / 2.0)
+        mn = f((np.float64(f(new_min + mn))) / 2.0)
+    return pc[first]
+
+
+@pytest.mark.parametrize("cull", [True, False])
+def test_oracle_scdf_matches_slow_restatement(oracle, cull):
+    pc = scene_cloud(700, 3)
+    want = slow_scdf(pc, 0.03, RANGE, ORIGIN, LO, HI, cull)
+    got = oracle.filter_scdf(pc, 0.03, RANGE, ORIGIN, LO, HI, cull)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    assert 20 < len(got) < len(pc)
+
+
+def test_oracle_scdf_properties(oracle):
+    pc = scene_cloud(20000, 5)
+    out = oracle.filter_scdf(pc, 0.02, RANGE, ORIGIN, LO, HI, True)
+    keys = {tuple(p) for p in pc.view(np.uint32).reshape(-1, 3).tolist()}
+    assert all(tuple(p) in keys for p in out.view(np.uint32).reshape(-1, 3).tolist())  # a subset of the input
+    d = np.linalg.norm(out[1:] - out[:-1], axis=1)
+    assert (d > 0.02 * 0.999).all()  # neighbours on the last curve are farther than min_dist apart
+    inside = (np.linalg.norm(out - ORIGIN, axis=1) < RANGE)
+    assert inside.sum() >= len(out) - 1  # only the reference's stray copy of point 0 may lie outside
+    assert 500 < len(out) < 8000
+
+
+def test_oracle_centervox_properties(oracle):
+    pc = scene_cloud(30000, 7)
+    vs = 0.03
+    out = oracle.filter_centervox(pc, vs, RANGE, ORIGIN, LO, HI)
+    width = float((HI - LO).max())
+    gw = min(255, int(np.ceil(width / vs)))
+    isf = np.float32(gw) / np.float32(width)
+    vox = np.clip(((out - LO) * isf).astype(np.int32), 0, 254)
+    assert len({tuple(v) for v in vox.tolist()}) == len(out)  # one point per voxel
+    # every retained point is the closest to its voxel centre among the inputs of that voxel
+    ok = (np.linalg.norm(pc - ORIGIN, axis=1) < RANGE) & ((pc >= LO) & (pc <= HI)).all(1)
+    cand = pc[ok]
+    cvox = np.clip(((cand - LO) * isf).astype(np.int32), 0, 254)
+    centre = LO + (cvox.astype(np.float32) + np.float32(0.5)) * np.float32(vs)
+    dsq = ((cand - centre) ** 2).sum(1)
+    best = {}
+    for v, d, p in zip(map(tuple, cvox.tolist()), dsq, cand):
+        if v not in best or d < best[v][0]:
+            best[v] = (d, p)
+    assert len(best) == len(out)
+    for v, p in zip(map(tuple, vox.tolist()), out):
+        assert np.allclose(best[v][1], p)
+    # pool exhaustion is reported where the reference throws: tiny voxels over a big cloud
+    assert oracle.filter_centervox(scene_cloud(90000, 9), 0.004, RANGE, ORIGIN, LO, HI) is None
+
+
+def test_filter_abi_rejects_bad_arguments(vamp):
+    with pytest.raises(ValueError):
+        vamp.filter_pointcloud(np.zeros((4, 3), np.float32), 0.02, 1.0, 0.03, ORIGIN, LO, HI, True, "voxelgrid")
+    pts, ns = vamp.filter_pointcloud(np.zeros((0, 3), np.float32), 0.02, 1.0, 0.03, ORIGIN, LO, HI, True, "scdf")
+    assert pts.shape == (0, 3)  # filter.hh:185-188: an empty cloud comes back empty (no device needed)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cull", [True, False])
+@pytest.mark.parametrize("n,seed,min_dist", [(5000, 11, 0.02), (120000, 12, 0.015), (300, 13, 0.05)])
+def test_gpu_scdf_matches_oracle(vamp, oracle, n, seed, min_dist, cull):
+    pc = scene_cloud(n, seed)
+    want = oracle.filter_scdf(pc, min_dist, RANGE, ORIGIN, LO, HI, cull)
+    got, ns = vamp.filter_pointcloud(pc, min_dist, RANGE, 0.03, ORIGIN, LO, HI, cull, "scdf")
+    assert got.shape == want.shape
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    assert ns > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,seed,vs", [(5000, 21, 0.03), (200000, 22, 0.0303), (64, 23, 0.2)])
+def test_gpu_centervox_matches_oracle(vamp, oracle, n, seed, vs):
+    pc = scene_cloud(n, seed)
+    want = oracle.filter_centervox(pc, vs, RANGE, ORIGIN, LO, HI)
+    got, ns = vamp.filter_pointcloud(pc, 0.0, RANGE, vs, ORIGIN, LO, HI, True, "centervox")
+    assert got.shape == want.shape
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_gpu_centervox_pool_exhaustion_is_a_status(vamp, oracle):
+    pc = scene_cloud(90000, 9)
+    assert oracle.filter_centervox(pc, 0.004, RANGE, ORIGIN, LO, HI) is None
+    with pytest.raises(vamp.VmvError) as ei:
+        vamp.filter_pointcloud(pc, 0.0, RANGE, 0.004, ORIGIN, LO, HI, True, "centervox")
+    assert ei.value.status == 4  # VMV_ERR_CAPACITY

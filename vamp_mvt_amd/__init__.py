@@ -21,7 +21,7 @@ import numpy as np
 from . import _lib
 from ._lib import VmvError, check, lib
 
-__all__ = ["Sphere", "Cuboid", "Cylinder", "HeightField", "make_heightfield", "png_to_heightfield", "Environment", "robots", "device_count", "set_device", "abi_version",
+__all__ = ["Sphere", "Cuboid", "Cylinder", "filter_pointcloud", "HeightField", "make_heightfield", "png_to_heightfield", "Environment", "robots", "device_count", "set_device", "abi_version",
            "VmvError", "unpack_bits", "POINT_RADIUS"]
 
 POINT_RADIUS = 0.0025  # reference src/vamp/constants.py:25
@@ -123,6 +123,26 @@ class Cuboid:
     x = property(lambda s: float(s.params[0]))
     y = property(lambda s: float(s.params[1]))
     z = property(lambda s: float(s.params[2]))
+
+
+def filter_pointcloud(pc, min_dist, max_range, voxel_size, origin, workcell_min, workcell_max, cull, filter_type,
+                      return_device_time=False):
+    """vamp.filter_pointcloud (bindings/environment.cc:183-239) -> (points [m][3] float32, nanoseconds).
+    filter_type "scdf" = collision/filter.hh:175-275, "centervox" = collision/filter_centervox.hh; both run on the GPU
+    and return the reference's points in the reference's order.  (The reference returns an empty list for any other
+    filter_type; this raises, as its Python caller src/vamp/pointcloud.py:145 does.)"""
+    if filter_type not in ("scdf", "centervox"):
+        raise ValueError("filter_type must be one of: 'scdf', 'centervox'")
+    pts = _f32(pc).reshape(-1, 3)
+    n = pts.shape[0]
+    out = np.zeros((max(n, 1), 3), np.float32)
+    m, ns, dns = ctypes.c_size_t(0), ctypes.c_uint64(0), ctypes.c_uint64(0)
+    check(lib.vmv_filter_pointcloud(_fp(pts), n, float(min_dist), float(max_range), float(voxel_size), _fp(_f32(origin)),
+                                    _fp(_f32(workcell_min)), _fp(_f32(workcell_max)), int(bool(cull)),
+                                    0 if filter_type == "scdf" else 1, _fp(out), n, ctypes.byref(m), ctypes.byref(ns),
+                                    ctypes.byref(dns)), "vmv_filter_pointcloud")
+    res = out[:m.value].copy()
+    return (res, int(ns.value), int(dns.value)) if return_device_time else (res, int(ns.value))
 
 
 class HeightField:
