@@ -96,6 +96,11 @@ int vmv_env_heightfield_count(const vmv_env *env, size_t *count);
  * collision/capt.hh:296-369.  points: host pointer, [n][3] fp32. */
 int vmv_env_add_capt_pointcloud(vmv_env *env, const float *points_xyz, size_t n, float r_min, float r_max,
                                 float r_point, uint64_t *build_nanoseconds);
+/* The same point cloud structure built on the GPU: identical arrays, level-synchronous build
+ * (csrc/vmv_capt_gpu.hip).  build_nanoseconds: wall time including the upload of the points and the download of the
+ * arrays; device_nanoseconds: HIP-event time of the build on the device alone.  Either may be NULL. */
+int vmv_env_add_capt_pointcloud_gpu(vmv_env *env, const float *points_xyz, size_t n, float r_min, float r_max,
+                                    float r_point, uint64_t *build_nanoseconds, uint64_t *device_nanoseconds);
 /* Environment.add_mvt_pointcloud(points, r_min, r_max, workspace_aabb_min, workspace_aabb_max, r_point) -> build ns
  * — environment.cc:164-177, collision/mvt.hh:147-170 (the fork's Multi-level Voxel Table).  Where the reference
  * throws inside its noexcept constructor (a pool it sized up front runs out: mvt.hh:66-70, 634-648), this returns

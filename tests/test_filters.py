@@ -162,3 +162,44 @@ def test_gpu_centervox_pool_exhaustion_is_a_status(vamp, oracle):
     with pytest.raises(vamp.VmvError) as ei:
         vamp.filter_pointcloud(pc, 0.0, RANGE, 0.004, ORIGIN, LO, HI, True, "centervox")
     assert ei.value.status == 4  # VMV_ERR_CAPACITY
+
+
+# ---- CAPT build on the GPU: identical arrays to the host builder (which the oracle pins, tests/test_capt_oracle.py) ----
+def _capt_arrays(vamp, pts, r_min, r_max, r_point, build):
+    e = vamp.Environment()
+    e.add_capt_pointcloud(pts, r_min, r_max, r_point, build=build)
+    return e.host_tables()["capt"][0]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,seed,radii", [(2000, 41, (0.012, 0.08)), (10000, 42, (0.015, 0.08)), (10000, 43, (0.012, 0.24)),
+                                          (3000, 44, (0.02, 0.5)), (17, 45, (0.012, 0.08)), (4096, 46, (0.012, 0.1))])
+def test_gpu_capt_build_equals_host_build(vamp, n, seed, radii):
+    from vamp_mvt_amd.workloads import shell_cloud
+    pts = shell_cloud(n, seed)
+    a = _capt_arrays(vamp, pts, radii[0], radii[1], 0.0025, "host")
+    b = _capt_arrays(vamp, pts, radii[0], radii[1], 0.0025, "gpu")
+    assert a["nlog2"] == b["nlog2"]
+    for key in ("tests", "aff_starts", "aabbs", "aff", "aabb_top"):
+        assert a[key].shape == b[key].shape, key
+        assert np.array_equal(a[key].view(np.uint32), b[key].view(np.uint32)), key
+
+
+@pytest.mark.gpu
+def test_gpu_capt_build_drives_validation(vamp, oracle):
+    """an environment whose point cloud was built on the GPU validates exactly like the oracle's"""
+    from envs import build_oracle_env, spec_for
+    spec = spec_for("capt", "fetch")
+    oe = build_oracle_env(oracle, spec)
+    e = vamp.Environment()
+    for kind, p in spec:
+        if kind == "sphere":
+            e.add_sphere(vamp.Sphere(p[:3], p[3]))
+        elif kind == "cuboid":
+            e.add_cuboid(vamp.Cuboid.from_canonical(p))
+        else:
+            e.add_capt_pointcloud(*p, build="gpu")
+    rid = oracle.robot("fetch")
+    lo, span = oracle.bounds(rid)
+    q = (lo + span * np.random.default_rng(3).random((6000, len(lo)), dtype=np.float32)).astype(np.float32)
+    assert np.array_equal(vamp.fetch.validate_batch(q, e), oracle.validate_batch(rid, oe, q, threads=8))

@@ -47,5 +47,25 @@ def main():
                               "cpu_oracle_ms_1core": cpu * 1e3, "identical": bool(np.array_equal(pts, ref))}), flush=True)
 
 
+def capt_cases():
+    from vamp_mvt_amd.workloads import RADII, shell_cloud
+    for robot, n in (("panda", 10_000), ("fetch", 10_000), ("baxter", 10_000), ("panda", 65_536), ("fetch", 65_536)):
+        r_min, r_max = RADII[robot]
+        pts = shell_cloud(n, 51)
+        e = vamp.Environment()
+        e.add_capt_pointcloud(pts, r_min, r_max, vamp.POINT_RADIUS, build="gpu")  # warm up
+        gpu = [vamp.Environment().add_capt_pointcloud(pts, r_min, r_max, vamp.POINT_RADIUS, build="gpu", return_device_time=True)
+               for _ in range(3)]
+        host = [vamp.Environment().add_capt_pointcloud(pts, r_min, r_max, vamp.POINT_RADIUS) for _ in range(2)]
+        t = vamp.Environment()
+        t.add_capt_pointcloud(pts, r_min, r_max, vamp.POINT_RADIUS, build="gpu")
+        print(json.dumps({"case": "capt_build", "robot_radii": robot, "points": n,
+                          "affordance_vectors": int(t.host_tables()["capt"][0]["aff"].shape[1]),
+                          "gpu_ms_device": min(g[1] for g in gpu) / 1e6,
+                          "gpu_ms_wall_incl_upload": min(g[0] for g in gpu) / 1e6,
+                          "host_builder_ms_1core": min(host) / 1e6}), flush=True)
+
+
 if __name__ == "__main__":
+    capt_cases()
     main()

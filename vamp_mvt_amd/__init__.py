@@ -242,23 +242,30 @@ class Environment:
         self._ops.append(("heightfield", heightfield))
         self._dirty()
 
-    def add_capt_pointcloud(self, points, r_min, r_max, r_point):
-        """-> CAPT build time in nanoseconds (environment.cc:152-163)."""
+    def add_capt_pointcloud(self, points, r_min, r_max, r_point, build="host", return_device_time=False):
+        """-> CAPT build time in nanoseconds (environment.cc:152-163).  build="gpu" builds the same arrays on the
+        device (csrc/vmv_capt_gpu.hip); with return_device_time also the HIP-event time of the device work alone."""
+        if build not in ("host", "gpu"):
+            raise ValueError("build must be 'host' or 'gpu'")
         pts = _f32(points)
         if pts.ndim != 2 or pts.shape[1] != 3:
             raise TypeError("points must be [n][3]")
-        self._ops.append(("capt", (pts.copy(), float(r_min), float(r_max), float(r_point))))
+        self._ops.append(("capt_gpu" if build == "gpu" else "capt", (pts.copy(), float(r_min), float(r_max), float(r_point))))
         self._dirty()
         # build once now to report the time, as the reference does
         h = ctypes.c_void_p()
         check(lib.vmv_env_create(ctypes.byref(h)), "vmv_env_create")
-        ns = ctypes.c_uint64(0)
+        ns, dns = ctypes.c_uint64(0), ctypes.c_uint64(0)
         try:
-            check(lib.vmv_env_add_capt_pointcloud(h, _fp(pts), pts.shape[0], r_min, r_max, r_point, ctypes.byref(ns)),
-                  "vmv_env_add_capt_pointcloud")
+            if build == "gpu":
+                check(lib.vmv_env_add_capt_pointcloud_gpu(h, _fp(pts), pts.shape[0], r_min, r_max, r_point, ctypes.byref(ns),
+                                                          ctypes.byref(dns)), "vmv_env_add_capt_pointcloud_gpu")
+            else:
+                check(lib.vmv_env_add_capt_pointcloud(h, _fp(pts), pts.shape[0], r_min, r_max, r_point, ctypes.byref(ns)),
+                      "vmv_env_add_capt_pointcloud")
         finally:
             lib.vmv_env_destroy(h)
-        return int(ns.value)
+        return (int(ns.value), int(dns.value)) if return_device_time else int(ns.value)
 
     def add_mvt_pointcloud(self, points, r_min, r_max, workspace_aabb_min, workspace_aabb_max, r_point):
         """-> MVT build time in nanoseconds (environment.cc:164-177).  Raises VmvError(VMV_ERR_CAPACITY) where the
@@ -304,6 +311,10 @@ class Environment:
                     pts, r_min, r_max, lo, hi, r_point = arg
                     check(lib.vmv_env_add_mvt_pointcloud(h, _fp(pts), pts.shape[0], r_min, r_max, _fp(lo), _fp(hi),
                                                          r_point, None, None), "vmv_env_add_mvt_pointcloud")
+                elif kind == "capt_gpu":
+                    pts, r_min, r_max, r_point = arg
+                    check(lib.vmv_env_add_capt_pointcloud_gpu(h, _fp(pts), pts.shape[0], r_min, r_max, r_point, None, None),
+                          "vmv_env_add_capt_pointcloud_gpu")
                 else:
                     pts, r_min, r_max, r_point = arg
                     check(lib.vmv_env_add_capt_pointcloud(h, _fp(pts), pts.shape[0], r_min, r_max, r_point, None),

@@ -77,6 +77,7 @@ def _load():
         "vmv_env_add_capsule": (I, [V, c_float_p]),
         "vmv_filter_pointcloud": (I, [c_float_p, S, F, F, F, c_float_p, c_float_p, c_float_p, I, I, c_float_p, S, c_size_p,
                                       c_u64_p, c_u64_p]),
+        "vmv_env_add_capt_pointcloud_gpu": (I, [V, c_float_p, S, F, F, F, c_u64_p, c_u64_p]),
         "vmv_env_add_heightfield": (I, [V, c_float_p, c_float_p, S, S, c_float_p]),
         "vmv_env_heightfield_count": (I, [V, c_size_p]),
         "vmv_env_add_capt_pointcloud": (I, [V, c_float_p, S, F, F, F, c_u64_p]),

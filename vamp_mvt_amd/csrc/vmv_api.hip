@@ -372,6 +372,28 @@ extern "C"
         return VMV_OK;
     }
 
+    int vmv_env_add_capt_pointcloud_gpu(vmv_env *env, const float *pts, size_t n, float r_min, float r_max, float r_point,
+                                        uint64_t *build_ns, uint64_t *device_ns)
+    {
+        VMV_MUTABLE(env)
+        if (!pts || n < 2) return VMV_ERR_INVALID_ARGUMENT;
+        if (env->capts.size() >= (size_t) vmv::kMaxCapt) return VMV_ERR_CAPACITY;
+        int rc = require_device();
+        if (rc != VMV_OK) return rc;
+        const auto t0 = std::chrono::steady_clock::now();
+        vmv::CaptArrays arrays;
+        rc = vmv::build_capt_device(pts, n, r_min, r_max, r_point, arrays, device_ns);
+        if (rc != VMV_OK) return rc;
+        for (void *p : {(void *) arrays.dev.tests, (void *) arrays.dev.aff_starts, (void *) arrays.dev.aabbs, (void *) arrays.dev.aff})
+            if (p) env->allocations.push_back(p);  // freed with the environment
+        env->capts.push_back(std::move(arrays));
+        if (build_ns)
+            *build_ns = (uint64_t) std::chrono::duration_cast<std::chrono::nanoseconds>(
+                            std::chrono::steady_clock::now() - t0)
+                            .count();
+        return VMV_OK;
+    }
+
     int vmv_env_add_mvt_pointcloud(vmv_env *env, const float *pts, size_t n, float r_min, float r_max,
                                    const float *ws_min, const float *ws_max, float r_point, uint64_t *build_ns,
                                    int *reason)
@@ -498,8 +520,25 @@ extern "C"
         D.n_capt = (uint32_t) env->capts.size();
         for (size_t i = 0; i < env->capts.size(); ++i)
         {
-            const vmv::CaptArrays &a = env->capts[i];
+            vmv::CaptArrays &a = env->capts[i];
             vmv::CaptDev &c = D.capt[i];
+            if (a.dev.tests && a.dev.device == env->device)
+            {
+                // built on this device: use the arrays where they are
+                const size_t nv = a.dev.n_vectors;
+                c.tests = a.dev.tests;
+                c.aff_starts = a.dev.aff_starts;
+                c.aabbs = a.dev.aabbs;
+                c.aff_x = a.dev.aff;
+                c.aff_y = a.dev.aff + nv * 8;
+                c.aff_z = a.dev.aff + 2 * nv * 8;
+                std::memcpy(c.aabb_top, a.aabb_top, sizeof(c.aabb_top));
+                c.r_point = a.r_point;
+                c.nlog2 = a.nlog2;
+                c.n_tests = a.n_tests();
+                continue;
+            }
+            if ((rc = vmv::download_capt(a)) != VMV_OK) return rc;  // built on another device: go through the host
             if ((rc = upload(env, a.tests, &c.tests)) != VMV_OK) return rc;
             if ((rc = upload(env, a.aff_starts, &c.aff_starts)) != VMV_OK) return rc;
             if ((rc = upload(env, a.aabbs, &c.aabbs)) != VMV_OK) return rc;
@@ -511,7 +550,7 @@ extern "C"
             c.nlog2 = a.nlog2;
             c.n_tests = (uint32_t) a.tests.size();
         }
-        D.capt0_n_tests = D.n_capt ? (uint32_t) env->capts[0].tests.size() : 0u;
+        D.capt0_n_tests = D.n_capt ? env->capts[0].n_tests() : 0u;
         D.n_mvt = (uint32_t) env->mvts.size();
         for (size_t i = 0; i < env->mvts.size(); ++i)
         {
@@ -628,7 +667,9 @@ extern "C"
                             float *ax, float *ay, float *az, float *top)
     {
         if (!env || index >= env->capts.size()) return VMV_ERR_INVALID_ARGUMENT;
-        const vmv::CaptArrays &a = env->capts[index];
+        vmv::CaptArrays &a = const_cast<vmv_env *>(env)->capts[index];  // a GPU-built cloud is downloaded on first look
+        const int rc = vmv::download_capt(a);
+        if (rc != VMV_OK) return rc;
         if (tests) std::memcpy(tests, a.tests.data(), a.tests.size() * 4);
         if (aff_starts) std::memcpy(aff_starts, a.aff_starts.data(), a.aff_starts.size() * 4);
         if (aabbs) std::memcpy(aabbs, a.aabbs.data(), a.aabbs.size() * 4);

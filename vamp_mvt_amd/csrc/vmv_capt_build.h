@@ -33,7 +33,20 @@ namespace vmv
         std::array<std::vector<float>, 3> aff;  // n_vectors * 8 each
         float aabb_top[6];
         float r_min, r_max, r_point;
-        uint32_t n_aff_vectors() const { return static_cast<uint32_t>(aff[0].size() / 8); }
+        // device-resident copy (GPU build): the environment owns these allocations; the host vectors above are then
+        // filled on demand (inspection) and `resident` says which device holds the arrays
+        struct Device
+        {
+            float *tests = nullptr;
+            uint32_t *aff_starts = nullptr;
+            float *aabbs = nullptr;
+            float *aff = nullptr;  // x | y | z, n_vectors * 8 floats each
+            uint32_t n_vectors = 0;
+            int device = -1;
+        } dev;
+        bool host_valid = true;
+        uint32_t n_aff_vectors() const { return dev.tests ? dev.n_vectors : static_cast<uint32_t>(aff[0].size() / 8); }
+        uint32_t n_tests() const { return (1u << nlog2) - 1u; }
     };
 
     namespace capt_detail
@@ -207,4 +220,10 @@ namespace vmv
         }
         return true;
     }
+
+    // The same arrays built on the current HIP device (vmv_capt_gpu.hip).  They stay on the device (out.dev, owned by
+    // the caller from then on); download_capt fills the host vectors when somebody wants to look at them.
+    int build_capt_device(const float *xyz_host, size_t n, float r_min, float r_max, float r_point, CaptArrays &out,
+                          uint64_t *device_ns);
+    int download_capt(CaptArrays &a);
 }  // namespace vmv
