@@ -9,9 +9,11 @@
 //  then the greedy pass "keep a point iff it is farther than min_dist from the last KEPT point".  That pass is a
 //  chain i -> nxt(i) = first later point farther than min_dist from i, starting at 0; nxt is computed for every
 //  point in parallel and the chain is marked by pointer doubling (after round k every chain node within 2^(k+1)
-//  steps of the start is marked), then compacted with a prefix sum.  Restated quirks: see oracle/vamp_oracle.c
-//  (vo_filter_scdf) — `max` is the MIN of origin + range, the n - hi tail entries that refer to point 0, the x86
-//  float -> uint32 conversion of negative values.
+//  steps of the start is marked), then compacted with a prefix sum.  Restated quirks of the reference: `max` is the MIN of
+//  origin + range (filter.hh:193); the index vector is resized to n before culling, so the n - hi entries behind the
+//  survivors all refer to point 0 and take part in every later step (:195-216); remap_point converts a float to
+//  uint32_t, which the reference's x86-64 build does with cvttss2si to 64 bits and keeps the low half (negative values
+//  from those stray copies of point 0 do reach it).
 //
 //  centervox.  Every point atomically bids (distance² bits << 32 | index) for its voxel in a dense grid_width³ table
 //  (lowest distance wins, ties go to the lowest index = the reference's strict `<` on sequential insertion), and
@@ -92,7 +94,7 @@ namespace
         if (i < n && flags[i]) idx[pos[i]] = i;
     }
 
-    // float -> uint32 as the reference's x86-64 build converts it (cvttss2si to 64 bits, low half): see the oracle
+    // float -> uint32 as the reference's x86-64 build converts it (cvttss2si to 64 bits, low half; NaN / out of range -> 0)
     __device__ __forceinline__ uint32_t cvt_f32_u32_x86(float v)
     {
         if (!(v > -9223372036854775808.0f && v < 9223372036854775808.0f)) return 0u;
