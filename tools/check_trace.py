@@ -140,8 +140,33 @@ def check(name, n=20000, seed=1, verbose=True):
             if a != b:
                 print("    ref", a[:4], len(a[4]), a[4][:4], "\n    mod", b[:4], len(b[4]), b[4][:4])
                 break
+    # end-effector frame and attachment structure of Robot::fkcc_attach
+    progA = R.load_program(name, "fkcc_attach")
+    yA = R.Evaluator(progA, rv).run(q)
+    base = progA.n_y - 12
+    ee = eval_model(dict(ops=model["ee_ops"], outputs=[model["ee_outputs"][3 * i:3 * i + 3] for i in range(4)],
+                         radii=[0, 0, 0, 0]), q, rv)
+    mine = np.concatenate([ee[i, :3] for i in range(4)])
+    if not np.array_equal(mine.view(np.uint32), yA[base:base + 12].view(np.uint32)):
+        ok = False
+        print("  end-effector frame differs from fkcc_attach y[%d..%d]" % (base, base + 11))
+    if not np.array_equal(yA[:base].view(np.uint32), R.Evaluator(prog, rv).run(q).view(np.uint32)):
+        ok = False
+        print("  fkcc_attach computes different sphere centres than fkcc")
+    import re
+    txt = open(R.ROBOT_HH.format(name=name)).read()
+    seg = txt[txt.index("inline static bool fkcc_attach("):]
+    seg = seg[seg.index("// attaching at"):]
+    seg = seg[:seg.index("return true;")]
+    if not seg.startswith("// attaching at " + model["end_effector"]):
+        ok = False
+        print("  attachment frame differs:", seg[:60])
+    if re.findall(r"// Attachment vs\. (\S+)", seg) != model["attach_links"]:
+        ok = False
+        print("  attachment link list differs")
     max_err = float(np.abs(yref[:, :3] - ymod[:S, :3]).max())
-    print(f"{name}: {'BIT-EXACT' if ok else 'MISMATCH'} on {n} configs; {S} spheres; max |centre diff| = {max_err:.3e}")
+    print(f"{name}: {'BIT-EXACT' if ok else 'MISMATCH'} on {n} configs; {S} spheres + end-effector frame; "
+          f"max |centre diff| = {max_err:.3e}")
     return ok
 
 

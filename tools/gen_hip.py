@@ -154,6 +154,53 @@ CHUNK = 8  # fine spheres staged in the LDS slab at a time (slab = 1 bounding + 
 assert SPARSE_BATCH <= 8 and CHUNK <= 8  # vmv::kSelfScratchWords holds 8 * 64 list entries
 
 
+GRID_CLASSES = 4  # vmv::kGridClasses
+
+
+def grid_classes(m):
+    """Split the links into GRID_CLASSES classes by bounding radius (contiguous in sorted order), minimising the summed
+    candidate volume (R_class + typical primitive size + cell)^3 over the links.  -> (class radii, {link: class})"""
+    links = [(m["radii"][g["bound"]], g["link"]) for g in m["env_groups"]]
+    links.sort()
+    r = [x[0] for x in links]
+    n = len(r)
+    cost = lambda i, j: (j - i) * (r[j - 1] + 0.1) ** 3  # links i..j-1 share the radius r[j-1]
+    INF = float("inf")
+    best = [[INF] * (n + 1) for _ in range(GRID_CLASSES + 1)]
+    cut = [[0] * (n + 1) for _ in range(GRID_CLASSES + 1)]
+    best[0][0] = 0.0
+    for k in range(1, GRID_CLASSES + 1):
+        for j in range(1, n + 1):
+            for i in range(k - 1, j):
+                c = best[k - 1][i] + cost(i, j)
+                if c < best[k][j]:
+                    best[k][j], cut[k][j] = c, i
+    k = min(GRID_CLASSES, n)
+    bounds, j = [], n
+    while k > 0:
+        i = cut[k][j]
+        bounds.append((i, j))
+        j, k = i, k - 1
+    bounds.reverse()
+    radii, cls = [], {}
+    for ci, (i, j) in enumerate(bounds):
+        radii.append(r[j - 1])
+        for t in range(i, j):
+            cls[links[t][1]] = ci
+    while len(radii) < GRID_CLASSES:
+        radii.append(radii[-1])
+    return radii, cls
+
+
+def static_links(m):
+    """links whose spheres do not depend on the configuration"""
+    out = []
+    for g in m["env_groups"]:
+        if all(kind != "op" for s in [g["bound"]] + g["fine"] for kind, v in m["outputs"][s]):
+            out.append(g["link"])
+    return out
+
+
 def emit_robot(m):
     n = m["name"]
     L = []
@@ -197,14 +244,19 @@ def emit_robot(m):
     L.append("    __device__ __forceinline__ bool")
     L.append("    fkcc_env(const vmv::EnvView &E, const float (&q)[kDim], vmv::lds_ptr slab, const bool skip)")
     L.append("    {")
-    L.append("        bool bad = skip;")
+    L.append("        bool bad = skip || (E.dev->static_hit != 0u);")
     L.append("        // per-wave scratch words live right behind the sphere slab")
     L.append("        const vmv::lds_ptr scratch = slab - __lane_id() + kSlabSpheres * 3 * vmv::kRow;")
     em = Emitter(m)
+    class_radii, link_class = grid_classes(m)
+    static = set(static_links(m))
     for ln in links:
         g = env_by_link[ln]
         fine = g["fine"]
         chunks = [fine[i:i + CHUNK] for i in range(0, len(fine), CHUNK)]
+        if ln in static:
+            em.lines.append(f"        // ---- {ln}: static, evaluated once per environment (static_env_hit)")
+            continue
         em.lines.append(f"        // ---- {ln}: {len(fine)} spheres")
         em.need([g["bound"]] + fine)
 
@@ -216,8 +268,9 @@ def emit_robot(m):
         for si, s in enumerate(chunks[0]):
             stage(1 + si, s, "        ")
         em.lines.append("        {")
-        em.lines.append(f"            const bool gate = vmv::env_gate<G, Tab>(E, slab, scratch, {radii_off[ln]}, !bad);")
-        em.lines.append("            if (vmv::wave_any(gate))")
+        em.lines.append(f"            const bool gate = vmv::env_gate<G, Tab>(E, slab, scratch, {radii_off[ln]}, {link_class[ln]}, !bad);")
+        em.lines.append("            if (VMV_ABLATE_ENV >= 1) bad |= gate;  // measurement aid: no fine phase (wrong answers)")
+        em.lines.append("            else if (vmv::wave_any(gate))")
         em.lines.append("            {")
         done = 0
         for ci, ch in enumerate(chunks):
@@ -232,6 +285,29 @@ def emit_robot(m):
     L += em.lines
     L.append("        return bad;")
     L.append("    }")
+    L.append("")
+
+    # ---- static links ------------------------------------------------------------------------------------------
+    L.append("    // The environment groups of the links that never move, for every lane alike: run once per (environment, robot)")
+    L.append("    // by static_links_kernel; fkcc_env starts from its answer (EnvDev::static_hit) and skips these links.")
+    L.append("    __device__ __forceinline__ bool static_env_hit(const vmv::EnvView &E)")
+    L.append("    {")
+    L.append("        bool hit = false;")
+    for ln in links:
+        if ln not in static:
+            continue
+        g = env_by_link[ln]
+        b = g["bound"]
+        bc = [flit(m["outputs"][b][k][1]) for k in range(3)]
+        L.append(f"        if (vmv::env_hit<1, 0>(E, {bc[0]}, {bc[1]}, {bc[2]}, {flit(radii[b])}, true, nullptr))  // {ln}")
+        L.append("        {")
+        for s_ in g["fine"]:
+            c = [flit(m["outputs"][s_][k][1]) for k in range(3)]
+            L.append(f"            hit |= vmv::env_hit<1, 0>(E, {c[0]}, {c[1]}, {c[2]}, {flit(radii[s_])}, true, nullptr);")
+        L.append("        }")
+    L.append("        return hit;")
+    L.append("    }")
+    L.append(f"    constexpr int kNStaticLinks = {len(static)};")
     L.append("")
 
     # ---- self-collision half of fkcc -----------------------------------------------------------------------
@@ -468,6 +544,11 @@ def emit_robot(m):
     L.append(f"    static constexpr int kResolution = {n}::kResolution;")
     L.append(f"    static constexpr int kSlabSpheres = {n}::kSlabSpheres;")
     L.append(f"    static constexpr int kNRadii = {n}::kNRadii;")
+    L.append(f"    static constexpr int kNStaticLinks = {n}::kNStaticLinks;")
+    L.append("    static __device__ __forceinline__ bool static_env_hit(const vmv::EnvView &E)")
+    L.append("    {")
+    L.append(f"        return {n}::static_env_hit(E);")
+    L.append("    }")
     L.append(f"    static constexpr int kSelfBlocks = {SELF_BLOCKS.get(n, 2)};  // workgroups per CU the self-collision kernel is compiled for")
     L.append("    template <int G>")
     L.append("    static __device__ __forceinline__ bool")
@@ -515,8 +596,9 @@ def main(models):
         ds = ", ".join(flit(v) for v in m["descale"] + [0.0] * (16 - m["dimension"]))
         jn = ", ".join('"%s"' % j for j in m["joint_names"])
         max_bound = max(m["radii"][m["n_spheres"]:])
+        gr = ", ".join(flit(v) for v in grid_classes(m)[0])
         host.append(f'    {{"{m["name"]}", {m["dimension"]}, {m["n_spheres"]}, {m["resolution"]}, '
-                    f'{flit(m["min_radius"])}, {flit(m["max_radius"])}, {flit(max_bound)}, {{{lo}}}, {{{sp}}}, {{{ds}}}, '
+                    f'{flit(m["min_radius"])}, {flit(m["max_radius"])}, {flit(max_bound)}, {{{gr}}}, {{{lo}}}, {{{sp}}}, {{{ds}}}, '
                     f'"{m["end_effector"]}", {{{jn}}}}},')
     host.append("};")
     host.append(f"static const int kNumRobots = {len(models)};")

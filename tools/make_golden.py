@@ -51,8 +51,11 @@ def main():
             q[i] = rng.choice(np.array([0, np.pi / 2, -np.pi / 2, np.pi, np.pi / 4], np.float32), len(lo))
         y = R.Evaluator(prog, rv).run(q)  # [n_y, N]
         spheres = np.ascontiguousarray(y.reshape(-1, 4, q.shape[0]).transpose(2, 0, 1))  # [N][S][4]
+        # end-effector frame of Robot::fkcc_attach (its last 12 outputs: translation, rotation column-major)
+        ya = R.Evaluator(R.load_program(name, "fkcc_attach"), rv).run(q)
+        ee = np.ascontiguousarray(ya[-12:].T)  # [N][12]
         np.savez_compressed(os.path.join(OUT, f"fk_{name}.npz"), q=q, spheres=spheres,
-                            n_fine=np.int32(c["n_spheres"]))
+                            n_fine=np.int32(c["n_spheres"]), ee=ee)
         print(name, "fk golden", spheres.shape)
 
     c = R.robot_constants("panda")

@@ -176,7 +176,7 @@ class RefProgram:
 
 
 def load_program(name: str, function: str = "fkcc") -> RefProgram:
-    """Parse `function` ('fkcc' or 'sphere_fk') of robots/<name>.hh."""
+    """Parse `function` ('fkcc', 'fkcc_attach' or 'sphere_fk') of robots/<name>.hh."""
     path = ROBOT_HH.format(name=name)
     with open(path) as f:
         lines = f.read().split("\n")
@@ -184,6 +184,8 @@ def load_program(name: str, function: str = "fkcc") -> RefProgram:
         start = next(i for i, l in enumerate(lines) if "inline static bool fkcc(" in l)
     elif function == "sphere_fk":
         start = next(i for i, l in enumerate(lines) if "inline static void sphere_fk(" in l)
+    elif function == "fkcc_attach":
+        start = next(i for i, l in enumerate(lines) if "inline static bool fkcc_attach(" in l)
     else:
         raise ValueError(function)
     # body runs until the next top-level template/function declaration

@@ -519,7 +519,23 @@ def trace(urdf, srdf, joint_names, end_effector=None, bounding=None, resolution=
             self_groups.append(dict(a=a, b=b, bound_a=bound_index[a], bound_b=bound_index[b],
                                     pairs=[[s, t] for s in link_spheres[a] for t in link_spheres[b]]))
 
+    # end-effector frame (Robot::fkcc_attach / eefk: y[n_total*4 ..] = translation, then the rotation column-major):
+    # world frame of the movable joint composed with the frame's constant placement, as joint frames compose
+    ee_expr = None
+    if end_effector is not None:
+        jid, fr = link_frame[end_effector]
+        Rl, tl = const_R(fr.R), [P(v) for v in fr.t]
+        if oM[jid] is None:
+            Rw, tw = Rl, tl
+        else:
+            Rpar, tpar = oM[jid]
+            Rw = [[(Rpar[i][0] * Rl[0][k] + Rpar[i][1] * Rl[1][k]) + Rpar[i][2] * Rl[2][k] for k in range(3)]
+                  for i in range(3)]
+            tw = [tpar[i] + ((Rpar[i][0] * tl[0] + Rpar[i][1] * tl[1]) + Rpar[i][2] * tl[2]) for i in range(3)]
+        ee_expr = [tw[0], tw[1], tw[2]] + [Rw[i][k] for k in range(3) for i in range(3)]
+
     out = Traced()
+    out.ee_expr = ee_expr
     out.tape, out.spheres, out.n_fine = tape, spheres, n_fine
     out.env_groups, out.self_groups = env_groups, self_groups
     out.lower, out.upper = lower, upper
@@ -541,8 +557,10 @@ def _c15(c: float) -> float:
     return float("%.15g" % c)
 
 
-def lower(tr: Traced):
-    """Return (ops, outputs): ops = SSA list over fp32 values; outputs[s] = [x,y,z] each ('op',id)|('const',f32)."""
+def lower(tr: Traced, ee_only: bool = False):
+    """Return (ops, outputs): ops = SSA list over fp32 values; outputs[s] = [x,y,z] each ('op',id)|('const',f32).
+    ee_only: the program of the end-effector frame alone (12 outputs in one list), lowered with the use counts of the
+    tape that holds the spheres AND the frame (the reference's fkcc_attach), emitting only what the frame needs."""
     nodes = tr.tape.nodes
     # reachability + use counts over the pruned graph
     use = [0] * len(nodes)
@@ -552,6 +570,8 @@ def lower(tr: Traced):
         for e in sp["expr"]:
             if not e.is_param:
                 roots.append(e.n)
+    if ee_only:
+        roots += [e.n for e in tr.ee_expr if not e.is_param]
     stack = []
     for r in roots:
         use[r] += 1
@@ -632,6 +652,8 @@ def lower(tr: Traced):
         return ("v", r)
 
     outputs = []
+    if ee_only:
+        return ops, [("const", f32(e.c)) if e.is_param else ("op", value(e.n)[1]) for e in tr.ee_expr]
     for sp in tr.spheres:
         o = []
         for e in sp["expr"]:
@@ -671,12 +693,17 @@ def to_json(tr: Traced):
         bounding_joint_frame={sp["link"]: sp["joint_frame"] for sp in tr.spheres if sp.get("bounding")},
         bounding_static={sp["link"]: sp["static"] for sp in tr.spheres if sp.get("bounding")},
     )
+    if tr.ee_expr is not None:
+        # Robot::fkcc_attach / eefk: translation xyz, then the rotation column-major (vector/math.hh to_isometry)
+        ee_ops, ee_out = lower(tr, ee_only=True)
+        model["ee_ops"] = [[op, a, b] for (op, a, b) in ee_ops]
+        model["ee_outputs"] = [list(c) for c in ee_out]
     return model
 
 
 ROBOTS = {
     "panda": dict(urdf="panda/panda_spherized.urdf", srdf="panda/panda.srdf", resolution=32,
-                  end_effector="panda_grasptarget",
+                  end_effector="panda_grasptarget", attach_anchor="panda_hand",
                   # ~1e-18 of solver round-off the reference's generated code carries in the hand's bounding centre
                   # (robots/panda.hh fkcc, y[268..270]); recorded as model data so special configurations
                   # (e.g. q = 0, where everything else cancels) stay bit-exact.
@@ -684,14 +711,14 @@ ROBOTS = {
                   joints=["panda_joint1", "panda_joint2", "panda_joint3", "panda_joint4", "panda_joint5",
                           "panda_joint6", "panda_joint7"]),
     "ur5": dict(urdf="ur5/ur5_spherized.urdf", srdf="ur5/ur5.srdf", resolution=32,
-                end_effector="robotiq_85_base_link",
+                end_effector="robotiq_85_base_link", attach_anchor="fts_robotside",
                 # one pair the shipped ur5.srdf leaves enabled but the reference's generated checker never tests
                 # (robots/ur5.hh has no "wrist_2_link vs. fts_robotside" group); recorded as model data.
                 extra_disabled=[("wrist_2_link", "fts_robotside")],
                 joints=["shoulder_pan_joint", "shoulder_lift_joint", "elbow_joint", "wrist_1_joint",
                         "wrist_2_joint", "wrist_3_joint"]),
     "fetch": dict(urdf="fetch/fetch_spherized.urdf", srdf="fetch/fetch.srdf", resolution=32,
-                  end_effector="gripper_link",
+                  end_effector="gripper_link", attach_anchor="gripper_link",
                   # The smallest enclosing ball of a mirror-symmetric sphere set has y = 0 exactly; the generator
                   # the reference used left ~1e-17 of solver round-off there (robots/fetch.hh fkcc, bounding
                   # spheres of the three static links).  Recorded as model data so the boolean stays bit-exact.
@@ -705,7 +732,7 @@ ROBOTS = {
                   joints=["torso_lift_joint", "shoulder_pan_joint", "shoulder_lift_joint", "upperarm_roll_joint",
                           "elbow_flex_joint", "forearm_roll_joint", "wrist_flex_joint", "wrist_roll_joint"]),
     "baxter": dict(urdf="baxter/baxter_spherized.urdf", srdf="baxter/baxter.srdf", resolution=64,
-                   end_effector="right_gripper",
+                   end_effector="right_gripper", attach_anchor="r_gripper_r_finger_tip",
                    joints=["left_s0", "left_s1", "left_e0", "left_e1", "left_w0", "left_w1", "left_w2",
                            "right_s0", "right_s1", "right_e0", "right_e1", "right_w0", "right_w1", "right_w2"]),
 }
@@ -722,6 +749,11 @@ def main():
                    bounding=cfg.get("bounding"), bounding_residue=cfg.get("bounding_residue"),
                    extra_disabled=cfg.get("extra_disabled", ()))
         model = to_json(tr)
+        # Robot::fkcc_attach tests the attachment against the links the anchor link is tested against ("Attachment
+        # vs. <link>" blocks of robots/<robot>.hh), in link order; the anchor is recorded per robot above
+        anchor = cfg["attach_anchor"]
+        partners = {g["b"] if g["a"] == anchor else g["a"] for g in model["self_groups"] if anchor in (g["a"], g["b"])}
+        model["attach_links"] = [ln for ln in model["links"] if ln in partners]
         with open(os.path.join(outdir, n + ".json"), "w") as f:
             json.dump(model, f, separators=(",", ":"))
         print(n, "ops", len(model["ops"]), "spheres", model["n_spheres"], "+", model["n_bounding"],

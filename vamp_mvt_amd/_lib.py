@@ -10,7 +10,8 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvamp_mvt_amd.so")
+# VMV_LIBRARY: developer override (ablation builds of the same ABI made by tools/); the product is the in-tree library
+LIB_PATH = os.environ.get("VMV_LIBRARY") or os.path.join(_HERE, "libvamp_mvt_amd.so")
 HEADER_PATH = os.path.join(_HERE, "..", "include", "vamp_mvt_amd.h")
 
 c_float_p = ctypes.POINTER(ctypes.c_float)

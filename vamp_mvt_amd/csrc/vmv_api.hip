@@ -12,6 +12,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -28,6 +29,7 @@ struct vmv_robot_info
     const char *name;
     int dimension, n_spheres, resolution;
     float min_radius, max_radius, max_bounding_radius;
+    float grid_radius[4];  // largest bounding radius of each broad-phase grid class (vmv::kGridClasses)
     float lower[16], span[16], descale[16];
     const char *end_effector;
     const char *joint_names[16];
@@ -147,6 +149,14 @@ struct vmv_env
     bool finalized = false;
     int device = -1;
     vmv::EnvLaunch launch[8]{};  // per robot: host + device copies of the kernel-side description (grids differ)
+    // the robot-specific part (broad-phase grids, static links) is built on the robot's first use
+    vmv::EnvDev base{};
+    std::vector<vmv::GridPrim> grid_prims;
+    uint32_t grid_words = 0;
+    std::once_flag robot_once[8];
+    std::mutex robot_mutex;  // serialises the lazy builds (they append to `allocations`)
+    int robot_status[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    std::string robot_error[8];
     std::vector<void *> allocations;
 };
 
@@ -595,26 +605,9 @@ extern "C"
         }
         uint32_t total_words = 0;
         for (uint32_t n : {D.n_sphere, D.n_capsule, D.n_zcapsule, D.n_cuboid, D.n_zcuboid}) total_words += (n + 31u) / 32u;
-        const bool use_grid = std::getenv("VMV_NO_GRID") == nullptr;
-        for (int r = 0; r < kNumRobots; ++r)
-        {
-            vmv::EnvDev Dr = D_base;
-            vmv::GridArrays grid;
-            if (use_grid && !gp.empty() && vmv::build_grid(gp, total_words, (double) kRobots[r].max_bounding_radius, grid))
-            {
-                if ((rc = upload(env, grid.cells, &Dr.grid)) != VMV_OK) return rc;
-                for (int k = 0; k < 3; ++k)
-                {
-                    Dr.grid_dims[k] = grid.dims[k];
-                    Dr.grid_origin[k] = grid.origin[k];
-                }
-                Dr.grid_words = grid.words;
-                Dr.grid_inv_cell = grid.inv_cell;
-            }
-            env->launch[r].host = Dr;
-            std::vector<vmv::EnvDev> one(1, Dr);
-            if ((rc = upload(env, one, &env->launch[r].d_env)) != VMV_OK) return rc;
-        }
+        env->base = D_base;
+        env->grid_prims = std::move(gp);
+        env->grid_words = total_words;
         env->finalized = true;
         return VMV_OK;
     }
@@ -682,6 +675,72 @@ extern "C"
 }  // extern "C"
 
 // ---------------------------------------------------------------------------------------------------------
+// robot-specific part of a finalized environment, built on first use (thread safe; environments stay immutable
+// from the caller's point of view)
+// ---------------------------------------------------------------------------------------------------------
+namespace
+{
+    int build_robot_part(vmv_env *env, int r)
+    {
+        int rc;
+        int dev = -1;
+        VMV_HIP(hipGetDevice(&dev));
+        if (dev != env->device) VMV_HIP(hipSetDevice(env->device));
+        vmv::EnvDev Dr = env->base;
+        const bool use_grid = std::getenv("VMV_NO_GRID") == nullptr;
+        if (use_grid && !env->grid_prims.empty())
+        {
+            bool ok = true;
+            std::vector<vmv::GridArrays> grids(vmv::kGridClasses);
+            for (int c = 0; c < vmv::kGridClasses && ok; ++c)
+            {
+                if (c > 0 && kRobots[r].grid_radius[c] == kRobots[r].grid_radius[c - 1])
+                    grids[c] = grids[c - 1];
+                else
+                    ok = vmv::build_grid(env->grid_prims, env->grid_words, (double) kRobots[r].grid_radius[c], grids[c]);
+            }
+            if (ok)
+            {
+                for (int c = 0; c < vmv::kGridClasses; ++c)
+                {
+                    vmv::GridDev &g = Dr.grid[c];
+                    if ((rc = upload(env, grids[c].cells, &g.cells)) != VMV_OK) return rc;
+                    for (int k = 0; k < 3; ++k)
+                    {
+                        g.dims[k] = grids[c].dims[k];
+                        g.origin[k] = grids[c].origin[k];
+                    }
+                    g.inv_cell = grids[c].inv_cell;
+                }
+                Dr.grid_words = env->grid_words;
+            }
+        }
+        env->launch[r].host = Dr;
+        std::vector<vmv::EnvDev> one(1, Dr);
+        const vmv::EnvDev *d_env = nullptr;
+        if ((rc = upload(env, one, &d_env)) != VMV_OK) return rc;
+        env->launch[r].d_env = d_env;
+        rc = kLaunchers[r]->prepare(env->launch[r], const_cast<vmv::EnvDev *>(d_env));
+        if (dev != env->device) (void) hipSetDevice(dev);
+        return rc;
+    }
+
+    int ensure_robot(const vmv_env *cenv, int r)
+    {
+        vmv_env *env = const_cast<vmv_env *>(cenv);
+        std::call_once(env->robot_once[r],
+                       [&]()
+                       {
+                           std::lock_guard<std::mutex> lock(env->robot_mutex);
+                           env->robot_status[r] = build_robot_part(env, r);
+                           if (env->robot_status[r] != VMV_OK) env->robot_error[r] = g_last_error;
+                       });
+        if (env->robot_status[r] != VMV_OK) g_last_error = env->robot_error[r];
+        return env->robot_status[r];
+    }
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------
 // batched entry points
 // ---------------------------------------------------------------------------------------------------------
 extern "C"
@@ -692,6 +751,7 @@ extern "C"
         if (!env || !d_q || !d_bits) return VMV_ERR_INVALID_ARGUMENT;
         if (!env->finalized) return VMV_ERR_NOT_FINALIZED;
         if (n == 0) return VMV_OK;
+        if (int rc = ensure_robot(env, robot); rc != VMV_OK) return rc;
         return kLaunchers[robot]->validate(env->launch[robot], d_q, n, d_bits, static_cast<hipStream_t>(stream), 3);
     }
 
@@ -701,6 +761,7 @@ extern "C"
         if (!env || !d_q || !d_bits) return VMV_ERR_INVALID_ARGUMENT;
         if (!env->finalized) return VMV_ERR_NOT_FINALIZED;
         if (n == 0) return VMV_OK;
+        if (int rc = ensure_robot(env, robot); rc != VMV_OK) return rc;
         return kLaunchers[robot]->validate(env->launch[robot], d_q, n, d_bits, static_cast<hipStream_t>(stream), 1);
     }
 
@@ -719,6 +780,7 @@ extern "C"
         if (!env || !d_a || !d_b || !d_bits) return VMV_ERR_INVALID_ARGUMENT;
         if (!env->finalized) return VMV_ERR_NOT_FINALIZED;
         if (n == 0) return VMV_OK;
+        if (int rc = ensure_robot(env, robot); rc != VMV_OK) return rc;
         return kLaunchers[robot]->validate_motion(env->launch[robot], d_a, d_b, n, d_bits, static_cast<hipStream_t>(stream));
     }
 

@@ -29,6 +29,9 @@ namespace vmv
         int (*validate_motion)(const EnvLaunch &, const float *d_a, const float *d_b, size_t n, uint64_t *d_bits,
                                hipStream_t);
         int (*fk)(const float *d_q, size_t n, float *d_out, hipStream_t);
+        // once per (environment, robot), after the robot's EnvDev is on the device: evaluates the robot's static links
+        // against the environment and stores the answer in d_env->static_hit (synchronous)
+        int (*prepare)(const EnvLaunch &, EnvDev *d_env);
     };
 
     extern const RobotLaunchers kPandaLaunchers, kUr5Launchers, kFetchLaunchers, kBaxterLaunchers;

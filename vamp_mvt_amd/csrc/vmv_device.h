@@ -179,6 +179,14 @@ namespace vmv
     };
     constexpr int kMaxHeightFields = 4;
 
+    struct GridDev
+    {
+        const uint32_t *cells;
+        uint32_t dims[3];
+        float origin[3], inv_cell;
+    };
+    constexpr int kGridClasses = 4;
+
     struct EnvDev  // kernel argument (by value)
     {
         const float *prims;  // HBM image of the LDS primitive block
@@ -188,11 +196,15 @@ namespace vmv
         uint32_t off_md_sphere, off_md_capsule, off_md_zcapsule, off_md_cuboid, off_md_zcuboid;  // min_distance arrays
         // candidate words (32 primitives each) per list: first word index, and whether all lists fit kMaskWords
         uint32_t wbase_sphere, wbase_capsule, wbase_zcapsule, wbase_cuboid, wbase_zcuboid, masked_fine;
-        // broad-phase grid of the gate pass (vmv_grid_build.h; robot specific: built for the robot's largest bounding
-        // radius): candidate words per cell, or grid == nullptr -> counted loops over the whole lists
-        const uint32_t *grid;
-        uint32_t grid_dims[3], grid_words;
-        float grid_origin[3], grid_inv_cell;
+        // broad-phase grids of the gate pass (vmv_grid_build.h; robot specific): the robot's links are split into
+        // kGridClasses classes by bounding radius (tools/gen_hip.py) and each class has a grid built for its largest
+        // radius - a finger (r = 0.024 m) walks far fewer candidates than in a grid sized for the 0.18 m upper arm.
+        // Candidate words per cell; grid[0].cells == nullptr -> counted loops over the whole lists.
+        GridDev grid[kGridClasses];
+        uint32_t grid_words;
+        // "some static link of the robot (its spheres do not depend on the configuration) collides with this
+        // environment": evaluated once per (environment, robot) by static_links_kernel with the same device functions
+        uint32_t static_hit;
         uint32_t n_capt;
         uint32_t capt0_n_tests;  // size of capt[0].tests (candidate for LDS staging behind the primitive block)
         uint32_t n_mvt;
@@ -441,6 +453,9 @@ namespace vmv
     //   VMV_PRIMS_SCALAR = 0: from the LDS copy of the block (64-lane broadcast ds_read_b128).
 #ifndef VMV_PRIMS_SCALAR
 #define VMV_PRIMS_SCALAR 1
+#ifndef VMV_ABLATE_ENV
+#define VMV_ABLATE_ENV 0  // measurement aid (tools only): 1 = environment kernel without fine phase, 2 = FK only
+#endif
 #endif
 #if VMV_PRIMS_SCALAR
     using rec_cptr = const __attribute__((address_space(4))) float *;
@@ -742,19 +757,21 @@ namespace vmv
     // Gate pass of one bounding sphere through the broad-phase grid (same answer as env_hit<G, 1>).
     template <int G>
     __device__ __forceinline__ bool
-    env_hit_grid(const EnvView &E, float x, float y, float z, float r, bool active, lds_u32 *mask_lane)
+    env_hit_grid(const EnvView &E, const uint32_t cls, float x, float y, float z, float r, bool active, lds_u32 *mask_lane)
     {
         const env_cptr Dp = E.dev;
 #define D (*Dp)
+        const GridDev __attribute__((address_space(4))) *Gd = &Dp->grid[cls];
         const float ext = group_max<G>(sqrtf(dot3(x, y, z, x, y, z)) + r);
         const float rsq = r * r;
         // this lane's cell; outside the grid box nothing can be touched (vmv_grid_build.h)
-        const float fx = (x - D.grid_origin[0]) * D.grid_inv_cell, fy = (y - D.grid_origin[1]) * D.grid_inv_cell,
-                    fz = (z - D.grid_origin[2]) * D.grid_inv_cell;
-        const bool inside = active && fx >= 0.0f && fy >= 0.0f && fz >= 0.0f && fx < (float) D.grid_dims[0] &&
-                            fy < (float) D.grid_dims[1] && fz < (float) D.grid_dims[2];
+        const float inv_cell = Gd->inv_cell;
+        const float fx = (x - Gd->origin[0]) * inv_cell, fy = (y - Gd->origin[1]) * inv_cell, fz = (z - Gd->origin[2]) * inv_cell;
+        const uint32_t d1 = Gd->dims[1], d2 = Gd->dims[2];
+        const bool inside = active && fx >= 0.0f && fy >= 0.0f && fz >= 0.0f && fx < (float) Gd->dims[0] && fy < (float) d1 &&
+                            fz < (float) d2;
         const uint32_t ix = inside ? (uint32_t) fx : 0u, iy = inside ? (uint32_t) fy : 0u, iz = inside ? (uint32_t) fz : 0u;
-        const gu_cptr cell = (gu_cptr) D.grid + ((size_t) (ix * D.grid_dims[1] + iy) * D.grid_dims[2] + iz) * D.grid_words;
+        const gu_cptr cell = (gu_cptr) Gd->cells + ((size_t) (ix * d1 + iy) * d2 + iz) * D.grid_words;
         bool hit = false;
         list_grid<kSphere>(E, D.n_sphere, D.off_sphere, D.wbase_sphere, cell, x, y, z, r, rsq, ext, inside, hit, mask_lane);
         list_grid<kCapsule>(E, D.n_capsule, D.off_capsule, D.wbase_capsule, cell, x, y, z, r, rsq, ext, inside, hit, mask_lane);
@@ -812,16 +829,18 @@ namespace vmv
     // `active` (rake-uniform) only prunes work.  Tab::radius(i) reads the robot's __constant__ radius table.
     template <int G, typename Tab>
     __device__ __noinline__ bool
-    env_gate(const EnvView E_, lds_cptr slab, lds_ptr scratch_, const int radius_index_, const bool active)
+    env_gate(const EnvView E_, lds_cptr slab, lds_ptr scratch_, const int radius_index_, const int grid_class_,
+             const bool active)
     {
         const uint32_t lane = __lane_id();
         const EnvView E{uniform(E_.dev), uniform(E_.lds), uniform(E_.capt0_planes_in_lds), uniform(E_.radii)};
         lds_u32 *list = (lds_u32 *) uniform((lds_cptr) scratch_);
         lds_u32 *mask_lane = list + 2 * kWave + 4 + lane;
+        if (VMV_ABLATE_ENV >= 2) return slab[0] > 1e30f;  // measurement aid: FK only (keeps the FK results alive)
         bool own;
-        if (E.dev->masked_fine && E.dev->grid != nullptr)
-            own = env_hit_grid<G>(E, slab[0], slab[kRow], slab[2 * kRow], Tab::radius(uniform(radius_index_)), active,
-                                  mask_lane);
+        if (E.dev->masked_fine && E.dev->grid[0].cells != nullptr)
+            own = env_hit_grid<G>(E, (uint32_t) uniform(grid_class_), slab[0], slab[kRow], slab[2 * kRow],
+                                  Tab::radius(uniform(radius_index_)), active, mask_lane);
         else if (E.dev->masked_fine)
         {
 #pragma unroll
