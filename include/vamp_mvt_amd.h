@@ -92,6 +92,13 @@ int vmv_env_add_capsule(vmv_env *env, const float *params8);
 int vmv_env_add_heightfield(vmv_env *env, const float *center3, const float *scale3, size_t xd, size_t yd,
                             const float *data);
 int vmv_env_heightfield_count(const vmv_env *env, size_t *count);
+/* Environment.attach(Attachment) / detach — bindings/environment.cc:178-181; Attachment(tf) + add_sphere(s)
+ * (:241-259), collision/attachments.hh.  tf: 4 x 4 row-major, the attachment's frame relative to the end-effector
+ * frame; spheres: [n][4] = x y z r in that frame, n <= 256.  With an attachment (and n > 0) every validate call is
+ * Robot::fkcc_attach (planning/validate.hh:43,58): plain fkcc, then the posed spheres against the environment and
+ * against the links of the reference's "Attachment vs. <link>" blocks. */
+int vmv_env_attach(vmv_env *env, const float *tf_rowmajor_4x4, const float *spheres_xyzr, size_t n);
+int vmv_env_detach(vmv_env *env);
 /* Environment.add_capt_pointcloud(points, r_min, r_max, r_point) -> build ns — environment.cc:152-163,
  * collision/capt.hh:296-369.  points: host pointer, [n][3] fp32. */
 int vmv_env_add_capt_pointcloud(vmv_env *env, const float *points_xyz, size_t n, float r_min, float r_max,
@@ -131,6 +138,8 @@ int vmv_env_capt_arrays(const vmv_env *env, size_t index, float *tests, uint32_t
 /* <robot>.fk(q) -> list[Sphere] — robot_helper.hh:234-247, Robot::sphere_fk (robots/panda.hh:116-462).
  * d_out: [n][n_spheres][4] = x y z r. */
 int vmv_fk_batch(int robot, const float *d_q, size_t n, float *d_out, void *stream);
+/* <robot>.eefk(q) -> 4 x 4 — robot_helper.hh:279-282, Robot::eefk.  d_out: [n][16] row-major frames. */
+int vmv_eefk_batch(int robot, const float *d_q, size_t n, float *d_out, void *stream);
 /* <robot>.validate(q, env) — robot_helper.hh:255-267 -> validate_motion<Robot, 8, 1>(q, q, env)
  * (planning/validate.hh:70-77) -> Robot::fkcc (robots/panda.hh:5226-10262).  One bit per configuration. */
 int vmv_validate_batch(int robot, const vmv_env *env, const float *d_q, size_t n, uint64_t *d_bits, void *stream);
@@ -146,6 +155,7 @@ int vmv_validate_motion_batch(int robot, const vmv_env *env, const float *d_star
 
 /* host-buffer variants (copies included; the PCIe-inclusive path) */
 int vmv_fk_batch_host(int robot, const float *q, size_t n, float *out);
+int vmv_eefk_batch_host(int robot, const float *q, size_t n, float *out);
 int vmv_validate_batch_host(int robot, const vmv_env *env, const float *q, size_t n, uint64_t *bits);
 int vmv_validate_motion_batch_host(int robot, const vmv_env *env, const float *start, const float *goal, size_t n,
                                    uint64_t *bits);

@@ -194,6 +194,11 @@ struct vo_env
     size_t n_mvts;
     vo_heightfield *heightfields;
     size_t n_heightfields;
+    /* collision/attachments.hh: relative frame (row-major 3x4: R | t) + spheres (x y z r) in that frame */
+    int attached;
+    float attach_tf[12];
+    float *attach_spheres;
+    size_t n_attach_spheres;
 };
 
 vo_env *vo_env_create(void) { return (vo_env *) calloc(1, sizeof(vo_env)); }
@@ -234,6 +239,7 @@ void vo_env_destroy(vo_env *e)
     free(e->mvts);
     for (size_t i = 0; i < e->n_heightfields; ++i) free(e->heightfields[i].data);
     free(e->heightfields);
+    free(e->attach_spheres);
     free(e);
 }
 
@@ -333,6 +339,19 @@ void vo_env_add_capsule(vo_env *e, const float *p)
         qsort(e->capsules, e->n_capsules, sizeof(vo_capsule), cmp_capsule);
     }
 }
+
+/* Environment.attach / detach (bindings/environment.cc:178-181); Attachment(tf) + add_spheres (:241-259) */
+void vo_env_attach(vo_env *e, const float tf_rowmajor_4x4[16], const float *spheres_xyzr, size_t n)
+{
+    e->attached = 1;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 4; ++j) e->attach_tf[4 * i + j] = tf_rowmajor_4x4[4 * i + j];
+    free(e->attach_spheres);
+    e->attach_spheres = (float *) malloc((n ? n : 1) * 4 * sizeof(float));
+    memcpy(e->attach_spheres, spheres_xyzr, n * 4 * sizeof(float));
+    e->n_attach_spheres = n;
+}
+void vo_env_detach(vo_env *e) { e->attached = 0; }
 
 /* bindings/environment.cc:149-151 + factory.hh:365-386: scale -> reciprocal; no sorting, min_distance unused */
 int vo_env_add_heightfield(vo_env *e, const float center[3], const float scale[3], size_t xd, size_t yd, const float *data)
@@ -1124,6 +1143,9 @@ typedef struct
     size_t n_self_groups;
     const uint16_t (*self_pairs)[2];
     const float *lower, *span, *descale;
+    void (*ee_frame)(const float *q, float *out12); /* fkcc_attach's last 12 outputs: translation, rotation col-major */
+    const uint16_t *attach_groups;                  /* env_groups indices of the "Attachment vs. <link>" blocks */
+    size_t n_attach_groups;
 } vo_robot;
 
 #include "gen/robots_gen.inc"
@@ -1221,7 +1243,76 @@ static int fkcc_lanes(int robot, const vo_env *e, const float *block, const int 
         }
     }
 #undef SELF_HIT
+    if (!e->attached) return 1; /* planning/validate.hh:43,58: fkcc_attach only when the environment has attachments */
+
+    /* Robot::fkcc_attach (robots/panda.hh:15308-15445): pose the attachment at the end-effector frame
+     * (collision/attachments.hh:43-56: n_tf = p_tf * tf; sphere = n_tf * s), then attachment vs. environment
+     * (validity.hh:258-275) and attachment vs. the links of the "Attachment vs." blocks (validity.hh:277-303).
+     * PARITY UNPINNED: the two products are Eigen expressions on the vector type; restated here as the coefficient sums
+     * ((a0 b0 + a1 b1) + a2 b2) [+ t], the order Eigen's fixed-size 3-term redux uses.  Eigen is not available offline. */
+    static _Thread_local float A[256][3][VO_RAKE];
+    const size_t na = e->n_attach_spheres < 256 ? e->n_attach_spheres : 256;
+    for (int l = 0; l < lanes; ++l)
+    {
+        float q[16], f[12];
+        for (size_t j = 0; j < R->dimension; ++j) q[j] = block[j * VO_RAKE + l];
+        R->ee_frame(q, f);
+        const float *T = e->attach_tf; /* row-major 3x4 */
+        float Rn[3][3], tn[3];
+        for (int i = 0; i < 3; ++i)
+        {
+            /* p_tf rotation is column-major behind the translation: R(i, k) = f[3 + 3 k + i] (vector/math.hh:40-51) */
+            const float r0 = f[3 + i], r1 = f[6 + i], r2 = f[9 + i];
+            for (int j = 0; j < 3; ++j) Rn[i][j] = ((r0 * T[j]) + (r1 * T[4 + j])) + (r2 * T[8 + j]);
+            tn[i] = (((r0 * T[3]) + (r1 * T[7])) + (r2 * T[11])) + f[i];
+        }
+        for (size_t s = 0; s < na; ++s)
+        {
+            const float *sp = e->attach_spheres + 4 * s;
+            for (int i = 0; i < 3; ++i) A[s][i][l] = (((Rn[i][0] * sp[0]) + (Rn[i][1] * sp[1])) + (Rn[i][2] * sp[2])) + tn[i];
+        }
+    }
+    for (size_t s = 0; s < na; ++s)
+        if (sphere_environment_in_collision(e, A[s][0], A[s][1], A[s][2], e->attach_spheres[4 * s + 3], lanes)) return 0;
+#define ATT_HIT(S, RES)                                                                                          \
+    do                                                                                                           \
+    {                                                                                                            \
+        (RES) = 0;                                                                                               \
+        for (size_t s_ = 0; s_ < na && !(RES); ++s_)                                                             \
+            for (int l = 0; l < lanes; ++l)                                                                      \
+                (RES) |= signbit_set(sphere_sphere_sql2(C[S][0][l], C[S][1][l], C[S][2][l], R->radii[S],         \
+                                                        A[s_][0][l], A[s_][1][l], A[s_][2][l],                   \
+                                                        e->attach_spheres[4 * s_ + 3]));                         \
+    } while (0)
+    for (size_t g = 0; g < R->n_attach_groups; ++g)
+    {
+        const vo_env_group *G = &R->env_groups[R->attach_groups[g]];
+        int hit;
+        ATT_HIT(G->bound, hit);
+        if (!hit) continue;
+        for (size_t f = 0; f < G->n_fine; ++f)
+        {
+            const unsigned s = R->env_fine[G->fine_offset + f];
+            ATT_HIT(s, hit);
+            if (hit) return 0;
+        }
+    }
+#undef ATT_HIT
     return 1;
+}
+
+/* Robot::eefk (robots/panda.hh, bindings/robot_helper.hh:279-282): 4x4 row-major */
+void vo_eefk(int robot, const float *q, float *out16)
+{
+    float f[12];
+    vo_robots[robot].ee_frame(q, f);
+    for (int i = 0; i < 3; ++i)
+    {
+        for (int k = 0; k < 3; ++k) out16[4 * i + k] = f[3 + 3 * k + i];
+        out16[4 * i + 3] = f[i];
+    }
+    out16[12] = out16[13] = out16[14] = 0.F;
+    out16[15] = 1.F;
 }
 
 int vo_fkcc_rake(int robot, const vo_env *e, const float *block) { return fkcc_lanes(robot, e, block, VO_RAKE); }

@@ -47,6 +47,11 @@ void vo_env_add_capsule(vo_env *e, const float *p8);
 /* make_heightfield + add_heightfield (collision/factory.hh:363-423, bindings/environment.cc:100,149-151): row-major
  * data[yd][xd]; `scale` as given to make_heightfield (the shape stores the reciprocals).  Returns 0 on success. */
 int vo_env_add_heightfield(vo_env *e, const float center[3], const float scale[3], size_t xd, size_t yd, const float *data);
+/* Environment.attach(Attachment(tf) + spheres) / detach (bindings/environment.cc:178-181, :241-259;
+ * collision/attachments.hh).  tf: 4x4 row-major, relative to the end-effector frame; spheres: [n][4] = x y z r in
+ * that frame (at most 256).  With an attachment the rake check is Robot::fkcc_attach (planning/validate.hh:43,58). */
+void vo_env_attach(vo_env *e, const float tf_rowmajor_4x4[16], const float *spheres_xyzr, size_t n);
+void vo_env_detach(vo_env *e);
 /* collision/capt.hh:296-369; returns 0 on success */
 int vo_env_add_capt(vo_env *e, const float *points_xyz, size_t n, float r_min, float r_max, float r_point);
 
@@ -122,6 +127,8 @@ float vo_l2_norm(const float *v, size_t dim);
 
 /* Robot::sphere_fk<1> (robots/panda.hh:116-462): out[n_spheres][4] = x y z r */
 void vo_fk(int robot, const float *q, float *out);
+/* Robot::eefk (bindings/robot_helper.hh:279-282): end-effector frame, 4x4 row-major */
+void vo_eefk(int robot, const float *q, float *out16);
 /* FK of fine + bounding spheres as used by fkcc: out[n_total][4] */
 void vo_fk_all(int robot, const float *q, float *out);
 

@@ -61,6 +61,16 @@ def spec_for(kind, robot="panda", seed=0):
         spec = shell_spec(seed + 5, 3, 3)
         spec.append(("mvt", (pts, r_min, r_max, lo, hi, POINT_RADIUS)))
         return spec
+    if kind in ("attach", "attach_free"):  # a held object: spheres attached at a frame relative to the end effector
+        rng = np.random.default_rng(seed + 17)
+        a = 0.4
+        tf = np.array([[np.cos(a), -np.sin(a), 0, 0.02], [np.sin(a), np.cos(a), 0, -0.01], [0, 0, 1, 0.06], [0, 0, 0, 1]],
+                      np.float32)
+        # a 25 cm rod along the attachment's z axis + a cross piece: 11 spheres (more than one slab chunk)
+        sp = [[0, 0, z, 0.03] for z in np.linspace(0.0, 0.25, 7)] + [[x, 0, 0.25, 0.025] for x in (-0.1, -0.05, 0.05, 0.1)]
+        spec = shell_spec(seed + 5, 5, 5) if kind == "attach" else []
+        spec.append(("attach", (tf, np.array(sp, np.float32))))
+        return spec
     if kind == "heightfield":  # terrain under/around the robot + a few primitives (sphere_heightfield.hh)
         rng = np.random.default_rng(seed + 13)
         xd, yd = 48, 48
@@ -86,6 +96,8 @@ def build_oracle_env(o, spec):
             e.add_cuboid(p)
         elif kind == "capsule":
             e.add_capsule(p)
+        elif kind == "attach":
+            e.attach(*p)
         elif kind == "heightfield":
             e.add_heightfield(*p)
         elif kind == "mvt":

@@ -61,6 +61,9 @@ class Oracle:
         L.vo_env_add_sphere.argtypes = [ctypes.c_void_p] + [ctypes.c_float] * 4
         L.vo_env_add_cuboid.argtypes = [ctypes.c_void_p, _fp]
         L.vo_env_add_capsule.argtypes = [ctypes.c_void_p, _fp]
+        L.vo_env_attach.argtypes = [ctypes.c_void_p, _fp, _fp, ctypes.c_size_t]
+        L.vo_env_detach.argtypes = [ctypes.c_void_p]
+        L.vo_eefk.argtypes = [ctypes.c_int, _fp, _fp]
         L.vo_env_add_heightfield.argtypes = [ctypes.c_void_p, _fp, _fp, ctypes.c_size_t, ctypes.c_size_t, _fp]
         L.vo_env_add_heightfield.restype = ctypes.c_int
         L.vo_env_add_capt.argtypes = [ctypes.c_void_p, _fp, ctypes.c_size_t] + [ctypes.c_float] * 3
@@ -104,6 +107,12 @@ class Oracle:
         L.vo_validate_batch.argtypes = [ctypes.c_int, ctypes.c_void_p, _fp, ctypes.c_size_t, _u8p]
         L.vo_validate_motion_batch.argtypes = [ctypes.c_int, ctypes.c_void_p, _fp, _fp, ctypes.c_size_t, _u8p]
         L.vo_validate_batch_mt.argtypes = [ctypes.c_int, ctypes.c_void_p, _fp, ctypes.c_size_t, _u8p, ctypes.c_int]
+
+    def eefk(self, rid, q):
+        out = np.zeros((4, 4), np.float32)
+        q = np.ascontiguousarray(q, np.float32)
+        self.L.vo_eefk(rid, _f(q), _f(out))
+        return out
 
     # -- point-cloud filters ---------------------------------------------------
     def filter_scdf(self, pc, min_dist, max_range, origin, lo, hi, cull):
@@ -221,6 +230,14 @@ class OracleEnv:
         p = np.ascontiguousarray(p15, np.float32)
         assert p.size == 15
         self.o.L.vo_env_add_cuboid(self.h, _f(p))
+
+    def attach(self, tf, spheres):
+        tf = np.ascontiguousarray(tf, np.float32).reshape(4, 4)
+        sp = np.ascontiguousarray(spheres, np.float32).reshape(-1, 4)
+        self.o.L.vo_env_attach(self.h, _f(tf), _f(sp), sp.shape[0])
+
+    def detach(self):
+        self.o.L.vo_env_detach(self.h)
 
     def add_heightfield(self, center, scale, xd, yd, data):
         c, sc, d = (np.ascontiguousarray(a, np.float32) for a in (center, scale, data))

@@ -11,7 +11,7 @@ from test_oracle_pins import mt19937_uniform_configs
 
 pytestmark = pytest.mark.gpu
 ROBOTS = ["panda", "ur5", "fetch", "baxter"]
-KINDS = ["empty", "cage", "shell64", "mixed", "capt", "heightfield"]
+KINDS = ["empty", "cage", "shell64", "mixed", "capt", "heightfield", "attach", "attach_free"]
 
 
 def uniform_configs(oracle, name, n, seed):
@@ -40,7 +40,7 @@ def test_validate_batch_bit_exact(vamp, oracle, name, kind):
 
 
 @pytest.mark.parametrize("name", ROBOTS)
-@pytest.mark.parametrize("kind", ["empty", "shell64", "mixed", "capt", "heightfield"])
+@pytest.mark.parametrize("kind", ["empty", "shell64", "mixed", "capt", "heightfield", "attach", "attach_free"])
 def test_validate_motion_batch_bit_exact(vamp, oracle, name, kind):
     """Edges with distinct configurations per rake lane: exercises the 8-lane "any lane" gating."""
     env, oenv = make_env(kind, oracle, name)
@@ -86,6 +86,32 @@ def test_fk_bit_exact_vs_golden_and_oracle(vamp, oracle, golden_dir, name):
     assert np.abs(got[..., :3] - g["spheres"][:, :n_fine, :3]).max() <= 1e-5  # north star tolerance (met at 0)
     spheres = getattr(vamp, name).fk(g["q"][3])
     assert len(spheres) == n_fine and abs(spheres[5].x - float(g["spheres"][3, 5, 0])) == 0.0
+
+
+@pytest.mark.parametrize("name", ROBOTS)
+def test_eefk_bit_exact_vs_reference_outputs(vamp, oracle, golden_dir, name):
+    """<robot>.eefk against the end-effector frame of the reference's generated fkcc_attach (tests/golden, `ee`)."""
+    g = np.load(os.path.join(golden_dir, f"fk_{name}.npz"))
+    got = getattr(vamp, name).eefk_batch(g["q"])
+    want = np.zeros((len(g["q"]), 4, 4), np.float32)
+    want[:, :3, 3] = g["ee"][:, :3]
+    want[:, :3, :3] = g["ee"][:, 3:].reshape(-1, 3, 3).transpose(0, 2, 1)  # the reference stores it column-major
+    want[:, 3, 3] = 1.0
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    assert np.array_equal(getattr(vamp, name).eefk(g["q"][5]), want[5])
+
+
+@pytest.mark.parametrize("name", ROBOTS)
+def test_attachment_changes_answers_and_detach_restores_them(vamp, oracle, name):
+    env, oenv = make_env("attach", oracle, name)
+    rid, q = uniform_configs(oracle, name, 8000, seed=21)
+    with_att = getattr(vamp, name).validate_batch(q, env)
+    assert np.array_equal(with_att, oracle.validate_batch(rid, oenv, q, threads=8))
+    env.detach()
+    oenv.detach()
+    without = getattr(vamp, name).validate_batch(q, env)
+    assert np.array_equal(without, oracle.validate_batch(rid, oenv, q, threads=8))
+    assert (without & ~with_att).sum() > 0 and (with_att & ~without).sum() == 0  # the attachment only removes validity
 
 
 def test_reference_known_answers_on_gpu(vamp, oracle, golden_dir):

@@ -525,6 +525,111 @@ def emit_robot(m):
     L.append(f"    constexpr int kSelfPasses = {len(batches)};")
     L.append("")
 
+    # ---- end-effector frame + attachments -----------------------------------------------------------------------
+    ee_m = dict(ops=m["ee_ops"], outputs=[m["ee_outputs"][3 * i:3 * i + 3] for i in range(4)])
+    L.append("    // Robot::eefk / the frame Robot::fkcc_attach poses attachments at: f[0..2] translation, f[3..11] rotation,")
+    L.append("    // column-major (vector/math.hh:40-51).  Own op tape (model key ee_ops), bit-exact vs the reference's outputs.")
+    L.append("    __device__ __forceinline__ void ee_frame(const float (&q)[kDim], float (&f)[12])")
+    L.append("    {")
+    em = Emitter(ee_m, prefix="e")
+    em.need([0, 1, 2, 3])
+    L += em.lines
+    for i in range(4):
+        for k in range(3):
+            L.append(f"        f[{3 * i + k}] = {em.coord(i, k)};")
+    L.append("    }")
+    L.append("")
+    L.append("    // The attachment part of Robot::fkcc_attach (robots/%s.hh; collision/attachments.hh, validity.hh:258-303):" % n)
+    L.append("    // pose the attached spheres at the end-effector frame, test them against the environment and against the")
+    L.append("    // links of the reference's \"Attachment vs. <link>\" blocks.  true = this rake collides.  The two frame")
+    L.append("    // products are Eigen expressions in the reference (parity unpinned); restated as ((a0 b0 + a1 b1) + a2 b2) [+ t].")
+    L.append("    template <int G>")
+    L.append("    __device__ __forceinline__ bool")
+    L.append("    fkcc_attach(const vmv::EnvView &E, const float (&q)[kDim], vmv::lds_ptr slab, const bool skip)")
+    L.append("    {")
+    L.append("        bool bad = skip;")
+    L.append("        const vmv::lds_ptr scratch = slab - __lane_id() + kSlabSpheres * 3 * vmv::kRow;")
+    L.append("        const vmv::env_cptr Dp = E.dev;")
+    L.append("        const unsigned na = Dp->n_attach;")
+    L.append("        float f[12];")
+    L.append("        ee_frame(q, f);")
+    L.append("        float Rn[3][3], tn[3];")
+    L.append("#pragma unroll")
+    L.append("        for (int i = 0; i < 3; ++i)")
+    L.append("        {")
+    L.append("            const float r0 = f[3 + i], r1 = f[6 + i], r2 = f[9 + i];")
+    L.append("#pragma unroll")
+    L.append("            for (int j = 0; j < 3; ++j)")
+    L.append("                Rn[i][j] = ((r0 * Dp->attach_tf[j]) + (r1 * Dp->attach_tf[4 + j])) + (r2 * Dp->attach_tf[8 + j]);")
+    L.append("            tn[i] = (((r0 * Dp->attach_tf[3]) + (r1 * Dp->attach_tf[7])) + (r2 * Dp->attach_tf[11])) + f[i];")
+    L.append("        }")
+    L.append("        const vmv::cf_cptr sph = (vmv::cf_cptr) Dp->attach_spheres;  // wave-uniform indices: scalar loads")
+    L.append("        auto posed = [&](const unsigned s, float &x, float &y, float &z, float &r)")
+    L.append("        {")
+    L.append("            const float sx = sph[4 * s], sy = sph[4 * s + 1], sz = sph[4 * s + 2];")
+    L.append("            r = sph[4 * s + 3];")
+    L.append("            x = (((Rn[0][0] * sx) + (Rn[0][1] * sy)) + (Rn[0][2] * sz)) + tn[0];")
+    L.append("            y = (((Rn[1][0] * sx) + (Rn[1][1] * sy)) + (Rn[1][2] * sz)) + tn[1];")
+    L.append("            z = (((Rn[2][0] * sx) + (Rn[2][1] * sy)) + (Rn[2][2] * sz)) + tn[2];")
+    L.append("        };")
+    L.append("        // attachment vs. environment: chunks of posed spheres through the slab, re-dealt like a link's fine spheres")
+    att_chunk = slab_spheres - 1  # the slab holds 1 + min(CHUNK, largest link) spheres
+    L.append(f"        for (unsigned base = 0; base < na; base += {att_chunk}u)")
+    L.append("        {")
+    L.append(f"            const unsigned cnt = (na - base < {att_chunk}u) ? na - base : {att_chunk}u;")
+    L.append("            for (unsigned s = 0; s < cnt; ++s)")
+    L.append("            {")
+    L.append("                float x, y, z, r;")
+    L.append("                posed(base + s, x, y, z, r);")
+    L.append("                slab[(3 * (s + 1) + 0) * vmv::kRow] = x;")
+    L.append("                slab[(3 * (s + 1) + 1) * vmv::kRow] = y;")
+    L.append("                slab[(3 * (s + 1) + 2) * vmv::kRow] = z;")
+    L.append("            }")
+    L.append("            const bool act = vmv::env_list_active<G>(scratch, !bad);")
+    L.append("            if (vmv::wave_any(act))")
+    L.append("            {")
+    L.append("                vmv::env_fine<G, Tab>(E, slab, scratch, (int) cnt, kNRadii + (int) base, 1);")
+    L.append("                bad |= act && vmv::group_any<G>(vmv::env_flag(scratch));")
+    L.append("            }")
+    L.append("        }")
+    L.append("        // attachment vs. robot")
+    em = Emitter(m)
+    for ln in m["attach_links"]:
+        g = env_by_link[ln]
+        b = g["bound"]
+        em.lines.append(f"        // ---- Attachment vs. {ln}")
+        em.need([b] + g["fine"])
+        em.lines.append("        {")
+        em.lines.append("            bool gate = false;")
+        em.lines.append("            for (unsigned s = 0; s < na; ++s)")
+        em.lines.append("            {")
+        em.lines.append("                float x, y, z, r;")
+        em.lines.append("                posed(s, x, y, z, r);")
+        em.lines.append(f"                const float rs = {flit(radii[b])} + r;")
+        em.lines.append(f"                gate |= vmv::neg(vmv::sql2_3({em.coord(b, 0)}, {em.coord(b, 1)}, {em.coord(b, 2)}, x, y, z) - rs * rs);")
+        em.lines.append("            }")
+        em.lines.append("            gate = vmv::group_any<G>(gate) && !bad;")
+        em.lines.append("            if (vmv::wave_any(gate))")
+        em.lines.append("            {")
+        em.lines.append("                bool h = false;")
+        em.lines.append("                for (unsigned s = 0; s < na; ++s)")
+        em.lines.append("                {")
+        em.lines.append("                    float x, y, z, r;")
+        em.lines.append("                    posed(s, x, y, z, r);")
+        for fs in g["fine"]:
+            em.lines.append("                    {")
+            em.lines.append(f"                        const float rs = {flit(radii[fs])} + r;")
+            em.lines.append(f"                        h |= vmv::neg(vmv::sql2_3({em.coord(fs, 0)}, {em.coord(fs, 1)}, {em.coord(fs, 2)}, x, y, z) - rs * rs);")
+            em.lines.append("                    }")
+        em.lines.append("                }")
+        em.lines.append("                bad |= gate && vmv::group_any<G>(h);")
+        em.lines.append("            }")
+        em.lines.append("        }")
+    L += em.lines
+    L.append("        return bad;")
+    L.append("    }")
+    L.append("")
+
     # ---- sphere_fk ----------------------------------------------------------------------------------------
     L.append("    // Robot::sphere_fk (reference robots/%s.hh): out[s] = (x, y, z, r) of the fine spheres." % n)
     L.append("    __device__ __forceinline__ void sphere_fk(const float (&q)[kDim], float4 *out)")
@@ -565,6 +670,16 @@ def emit_robot(m):
     L.append("    static __device__ __forceinline__ void sphere_fk(const float (&q)[kDim], float4 *out)")
     L.append("    {")
     L.append(f"        {n}::sphere_fk(q, out);")
+    L.append("    }")
+    L.append("    static __device__ __forceinline__ void ee_frame(const float (&q)[kDim], float (&f)[12])")
+    L.append("    {")
+    L.append(f"        {n}::ee_frame(q, f);")
+    L.append("    }")
+    L.append("    template <int G>")
+    L.append("    static __device__ __forceinline__ bool")
+    L.append("    fkcc_attach(const vmv::EnvView &E, const float (&q)[kDim], vmv::lds_ptr slab, const bool skip)")
+    L.append("    {")
+    L.append(f"        return {n}::fkcc_attach<G>(E, q, slab, skip);")
     L.append("    }")
     L.append("};")
     L.append("")

@@ -28,7 +28,7 @@ def main():
         mod = getattr(vamp, name)
         rid = o.robot(name)
         lo, span = o.bounds(rid)
-        for kind in ("empty", "cage", "shell64", "mixed", "capt", "mvt", "heightfield"):
+        for kind in ("empty", "cage", "shell64", "mixed", "capt", "mvt", "heightfield", "attach"):
             env, oenv = make_env(kind, o, name)
             n = 4096 if kind not in ("capt", "mvt") else 2048
             q = (lo + span * rng.random((n, len(lo)), dtype=np.float32)).astype(np.float32)

@@ -21,7 +21,7 @@ import numpy as np
 from . import _lib
 from ._lib import VmvError, check, lib
 
-__all__ = ["Sphere", "Cuboid", "Cylinder", "filter_pointcloud", "HeightField", "make_heightfield", "png_to_heightfield", "Environment", "robots", "device_count", "set_device", "abi_version",
+__all__ = ["Sphere", "Cuboid", "Cylinder", "Attachment", "filter_pointcloud", "HeightField", "make_heightfield", "png_to_heightfield", "Environment", "robots", "device_count", "set_device", "abi_version",
            "VmvError", "unpack_bits", "POINT_RADIUS"]
 
 POINT_RADIUS = 0.0025  # reference src/vamp/constants.py:25
@@ -123,6 +123,32 @@ class Cuboid:
     x = property(lambda s: float(s.params[0]))
     y = property(lambda s: float(s.params[1]))
     z = property(lambda s: float(s.params[2]))
+
+
+class Attachment:
+    """vamp.Attachment(tf) — bindings/environment.cc:241-269, collision/attachments.hh: spheres rigidly attached at a
+    frame `tf` (4 x 4) relative to the end effector.  add_sphere / add_spheres, relative_frame, set_ee_pose(tf) +
+    posed_spheres (host-side float arithmetic, for inspection; the kernels pose per configuration themselves)."""
+
+    def __init__(self, tf):
+        self.relative_frame = _f32(tf, (4, 4)).copy()
+        self.spheres = []
+        self.posed_spheres = []
+
+    def add_sphere(self, sphere: "Sphere"):
+        self.spheres.append(sphere)
+
+    def add_spheres(self, spheres):
+        self.spheres.extend(spheres)
+
+    def set_ee_pose(self, tf):
+        n_tf = (_f32(tf, (4, 4)).astype(np.float64) @ self.relative_frame.astype(np.float64))
+        self.posed_spheres = [Sphere((n_tf[:3, :3] @ np.array([s.x, s.y, s.z]) + n_tf[:3, 3]).astype(np.float32), s.r)
+                              for s in self.spheres]
+
+    def _arrays(self):
+        sp = np.array([[s.x, s.y, s.z, s.r] for s in self.spheres], np.float32).reshape(-1, 4)
+        return self.relative_frame.copy(), sp
 
 
 def filter_pointcloud(pc, min_dist, max_range, voxel_size, origin, workcell_min, workcell_max, cull, filter_type,
@@ -238,6 +264,16 @@ class Environment:
         self._ops.append(("capsule", capsule.params.copy()))
         self._dirty()
 
+    def attach(self, attachment: Attachment):
+        """Environment.attach (environment.cc:178-180): at most one attachment; a later one replaces it."""
+        self._ops = [op for op in self._ops if op[0] != "attach"]
+        self._ops.append(("attach", attachment._arrays()))
+        self._dirty()
+
+    def detach(self):
+        self._ops = [op for op in self._ops if op[0] != "attach"]
+        self._dirty()
+
     def add_heightfield(self, heightfield: HeightField):
         self._ops.append(("heightfield", heightfield))
         self._dirty()
@@ -304,6 +340,9 @@ class Environment:
                     check(lib.vmv_env_add_cuboid(h, _fp(arg)), "vmv_env_add_cuboid")
                 elif kind == "capsule":
                     check(lib.vmv_env_add_capsule(h, _fp(arg)), "vmv_env_add_capsule")
+                elif kind == "attach":
+                    tf, sp = arg
+                    check(lib.vmv_env_attach(h, _fp(tf), _fp(sp), sp.shape[0]), "vmv_env_attach")
                 elif kind == "heightfield":
                     check(lib.vmv_env_add_heightfield(h, _fp(arg.center), _fp(arg.scaling), arg.xd, arg.yd, _fp(arg.data)),
                           "vmv_env_add_heightfield")
@@ -437,6 +476,18 @@ class _Robot(types.ModuleType):
         """validate_motion<Robot, 8, resolution>(start, goal, env) — planning/validate.hh:70-77."""
         a, b = _f32(start, (self._dim,)), _f32(goal, (self._dim,))
         return bool(self.validate_motion_batch(a[None, :], b[None, :], environment)[0])
+
+    def eefk(self, configuration):
+        """<robot>.eefk(q) -> 4 x 4 end-effector frame — robot_helper.hh:279-282."""
+        return self.eefk_batch(_f32(configuration, (self._dim,))[None, :])[0]
+
+    def eefk_batch(self, configurations):
+        q = _f32(configurations)
+        if q.ndim != 2 or q.shape[1] != self._dim:
+            raise TypeError(f"expected [n][{self._dim}] configurations")
+        out = np.zeros((q.shape[0], 4, 4), np.float32)
+        check(lib.vmv_eefk_batch_host(self._id, _fp(q), q.shape[0], _fp(out)), "vmv_eefk_batch_host")
+        return out
 
     def fk(self, configuration):
         """<robot>.fk(q) -> list[Sphere] — robot_helper.hh:234-247."""

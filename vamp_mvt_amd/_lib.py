@@ -98,6 +98,10 @@ def _load():
         "vmv_validate_batch_self": (I, [I, V, S, V, V]),
         "vmv_validate_motion_batch": (I, [I, V, V, V, S, V, V]),
         "vmv_fk_batch_host": (I, [I, c_float_p, S, c_float_p]),
+        "vmv_eefk_batch": (I, [I, V, S, V, V]),
+        "vmv_eefk_batch_host": (I, [I, c_float_p, S, c_float_p]),
+        "vmv_env_attach": (I, [V, c_float_p, c_float_p, S]),
+        "vmv_env_detach": (I, [V]),
         "vmv_validate_batch_host": (I, [I, V, c_float_p, S, c_u64_p]),
         "vmv_validate_motion_batch_host": (I, [I, V, c_float_p, c_float_p, S, c_u64_p]),
         "vmv_halton_configs": (I, [I, ctypes.c_uint64, V, S, V]),

@@ -145,6 +145,9 @@ struct vmv_env
         std::vector<float> data;
     };
     std::vector<HeightField> heightfields;
+    bool attached = false;
+    float attach_tf[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};  // row-major 3 x 4 (R | t), relative to the end effector
+    std::vector<float> attach_spheres;                            // [n][4] = x y z r in that frame
 
     bool finalized = false;
     int device = -1;
@@ -357,6 +360,23 @@ extern "C"
         h.yd = yd;
         h.data.assign(data, data + xd * yd);
         env->heightfields.push_back(std::move(h));
+        return VMV_OK;
+    }
+    int vmv_env_attach(vmv_env *env, const float *tf16, const float *spheres, size_t n)
+    {
+        VMV_MUTABLE(env)
+        if (!tf16 || (n && !spheres)) return VMV_ERR_INVALID_ARGUMENT;
+        if (n > (size_t) vmv::kMaxAttachSpheres) return VMV_ERR_CAPACITY;
+        env->attached = true;
+        for (int i = 0; i < 12; ++i) env->attach_tf[i] = tf16[i];  // the first three rows of the row-major 4 x 4
+        env->attach_spheres.assign(spheres, spheres + 4 * n);
+        return VMV_OK;
+    }
+    int vmv_env_detach(vmv_env *env)
+    {
+        VMV_MUTABLE(env)
+        env->attached = false;
+        env->attach_spheres.clear();
         return VMV_OK;
     }
     int vmv_env_heightfield_count(const vmv_env *env, size_t *count)
@@ -579,6 +599,14 @@ extern "C"
             d.r_point = m.r_point;
             d.grid_width = m.grid_width;
         }
+        D.n_attach = 0;
+        if (env->attached && !env->attach_spheres.empty())
+        {
+            // (an attachment without spheres poses nothing and tests nothing: plain fkcc gives the same answers)
+            D.n_attach = (uint32_t) (env->attach_spheres.size() / 4);
+            std::memcpy(D.attach_tf, env->attach_tf, sizeof(D.attach_tf));
+            if ((rc = upload(env, env->attach_spheres, &D.attach_spheres)) != VMV_OK) return rc;
+        }
         D.n_heightfield = (uint32_t) env->heightfields.size();
         for (size_t i = 0; i < env->heightfields.size(); ++i)
         {
@@ -752,7 +780,7 @@ extern "C"
         if (!env->finalized) return VMV_ERR_NOT_FINALIZED;
         if (n == 0) return VMV_OK;
         if (int rc = ensure_robot(env, robot); rc != VMV_OK) return rc;
-        return kLaunchers[robot]->validate(env->launch[robot], d_q, n, d_bits, static_cast<hipStream_t>(stream), 3);
+        return kLaunchers[robot]->validate(env->launch[robot], d_q, n, d_bits, static_cast<hipStream_t>(stream), 7);
     }
 
     int vmv_validate_batch_env(int robot, const vmv_env *env, const float *d_q, size_t n, uint64_t *d_bits, void *stream)
@@ -790,6 +818,37 @@ extern "C"
         if (!d_q || !d_out) return VMV_ERR_INVALID_ARGUMENT;
         if (n == 0) return VMV_OK;
         return kLaunchers[robot]->fk(d_q, n, d_out, static_cast<hipStream_t>(stream));
+    }
+
+    int vmv_eefk_batch(int robot, const float *d_q, size_t n, float *d_out, void *stream)
+    {
+        if (!robot_ok(robot)) return VMV_ERR_UNKNOWN_ROBOT;
+        if (!d_q || !d_out) return VMV_ERR_INVALID_ARGUMENT;
+        if (n == 0) return VMV_OK;
+        return kLaunchers[robot]->eefk(d_q, n, d_out, static_cast<hipStream_t>(stream));
+    }
+    int vmv_eefk_batch_host(int robot, const float *q, size_t n, float *out)
+    {
+        if (!robot_ok(robot)) return VMV_ERR_UNKNOWN_ROBOT;
+        if (!q || !out) return VMV_ERR_INVALID_ARGUMENT;
+        if (n == 0) return VMV_OK;
+        int rc = require_device();
+        if (rc != VMV_OK) return rc;
+        const size_t qb = n * (size_t) kRobots[robot].dimension * 4, ob = n * 64;
+        float *dq = nullptr, *dout = nullptr;
+        VMV_HIP(hipMalloc((void **) &dq, qb));
+        if (hipMalloc((void **) &dout, ob) != hipSuccess)
+        {
+            (void) hipFree(dq);
+            return VMV_ERR_HIP;
+        }
+        rc = VMV_OK;
+        if (hipMemcpy(dq, q, qb, hipMemcpyHostToDevice) != hipSuccess) rc = VMV_ERR_HIP;
+        if (rc == VMV_OK) rc = vmv_eefk_batch(robot, dq, n, dout, nullptr);
+        if (rc == VMV_OK && hipMemcpy(out, dout, ob, hipMemcpyDeviceToHost) != hipSuccess) rc = VMV_ERR_HIP;
+        (void) hipFree(dq);
+        (void) hipFree(dout);
+        return rc;
     }
 
     // ---- host-buffer variants ----

@@ -24,7 +24,8 @@ namespace vmv
     // status codes are the VMV_* values of include/vamp_mvt_amd.h
     struct RobotLaunchers
     {
-        // stage bit 1 = environment kernel (writes the words), bit 2 = self-collision kernel (ANDs into them)
+        // stage bit 1 = environment kernel (writes the words), bit 2 = self-collision kernel, bit 4 = attachment kernel
+        // (both AND into them; the attachment kernel only runs for environments with an attachment)
         int (*validate)(const EnvLaunch &, const float *d_q, size_t n, uint64_t *d_bits, hipStream_t, int stages);
         int (*validate_motion)(const EnvLaunch &, const float *d_a, const float *d_b, size_t n, uint64_t *d_bits,
                                hipStream_t);
@@ -32,6 +33,7 @@ namespace vmv
         // once per (environment, robot), after the robot's EnvDev is on the device: evaluates the robot's static links
         // against the environment and stores the answer in d_env->static_hit (synchronous)
         int (*prepare)(const EnvLaunch &, EnvDev *d_env);
+        int (*eefk)(const float *d_q, size_t n, float *d_out16, hipStream_t);  // 4 x 4 row-major frames
     };
 
     extern const RobotLaunchers kPandaLaunchers, kUr5Launchers, kFetchLaunchers, kBaxterLaunchers;

@@ -212,12 +212,19 @@ namespace vmv
         MvtDev mvt[kMaxMvt];
         uint32_t n_heightfield;
         HeightFieldDev heightfield[kMaxHeightFields];
+        // collision/attachments.hh: spheres rigidly attached to the end-effector frame.  attach_tf = the attachment's
+        // frame relative to the end effector (row-major 3 x 4: R | t), attach_spheres = [n_attach][4] x y z r in it.
+        uint32_t n_attach;
+        float attach_tf[12];
+        const float *attach_spheres;
     };
+    constexpr int kMaxAttachSpheres = 256;
 
     // explicit address spaces for everything that crosses a non-inlined call: the constant space makes the
     // environment header scalar loads (s_load), the global space makes per-lane CAPT reads global_load (not flat)
     using env_cptr = const __attribute__((address_space(4))) EnvDev *;
     using gf_cptr = const __attribute__((address_space(1))) float *;
+    using cf_cptr = const __attribute__((address_space(4))) float *;
     using gu_cptr = const __attribute__((address_space(1))) uint32_t *;
     typedef __attribute__((address_space(1))) v4f g_v4f;
 
@@ -860,9 +867,25 @@ namespace vmv
         return gate;
     }
 
+    // Lists the lanes (whole rakes) that still need an answer, as env_gate does for the lanes whose gate fired.
+    template <int G>
+    __device__ __forceinline__ bool env_list_active(lds_ptr scratch_, const bool active)
+    {
+        const uint32_t lane = __lane_id();
+        lds_u32 *list = (lds_u32 *) uniform((lds_cptr) scratch_);
+        const bool a = group_any<G>(active);
+        const uint64_t mask = __ballot(a);
+        list[kWave + lane] = 0u;  // flags
+        if (a) list[__popcll(mask & ((1ull << lane) - 1ull))] = lane;
+        if (lane == 0) list[2 * kWave] = (uint32_t) __popcll(mask);
+        wave_lds_sync();
+        return a;
+    }
+
     template <int G, typename Tab>
     __device__ __noinline__ void
-    env_fine(const EnvView E_, lds_cptr slab, lds_ptr scratch_, const int n_fine_, const int radii_offset_)
+    env_fine(const EnvView E_, lds_cptr slab, lds_ptr scratch_, const int n_fine_, const int radii_offset_,
+             const int full_ = 0 /* 1: no candidate words (spheres without a bounding-sphere pass: attachments) */)
     {
         const uint32_t lane = __lane_id();
         const EnvView E{uniform(E_.dev), uniform(E_.lds), uniform(E_.capt0_planes_in_lds), uniform(E_.radii)};
@@ -871,7 +894,7 @@ namespace vmv
         const int n_fine = uniform(n_fine_), radii_offset = uniform(radii_offset_);
         const int k = (int) uniform(list[2 * kWave]);
         if (k == 0) return;
-        const bool masked = E.dev->masked_fine != 0u;
+        const bool masked = E.dev->masked_fine != 0u && uniform(full_) == 0;
         lds_cptr wave_slab = uniform(slab - lane);
         const int items = k * n_fine;
         const float inv_k = 1.0f / (float) k;

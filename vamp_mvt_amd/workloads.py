@@ -78,6 +78,11 @@ def environment_from_spec(spec):
             e.add_capsule(vamp.Cylinder.from_canonical(p))
         elif kind == "mvt":
             e.add_mvt_pointcloud(*p)
+        elif kind == "attach":
+            tf, spheres = p
+            a = vamp.Attachment(tf)
+            a.add_spheres([vamp.Sphere(sp[:3], sp[3]) for sp in spheres])
+            e.attach(a)
         elif kind == "heightfield":
             center, scale, xd, yd, data = p
             e.add_heightfield(vamp.make_heightfield(center, scale, (xd, yd), data))
