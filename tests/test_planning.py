@@ -37,6 +37,30 @@ def test_rrtc_solves_the_sphere_cage(vamp, oracle):
 
 
 @pytest.mark.gpu
+def test_fcit_batch_loop_solves_the_sphere_cage(vamp, oracle):
+    """lazy complete-graph search (the FCIT* loop in batch form): solves the cage, every path edge holds for the oracle,
+    and optimisation never makes the path longer"""
+    from vamp_mvt_amd.planning import FCITSettings, Halton, fcit
+
+    vamp.set_device(0)
+    env, oenv = make_env("cage", oracle)
+    res = fcit(vamp.panda, CAGE_START, CAGE_GOAL, env, FCITSettings(batch_size=400, max_samples=4000), Halton(vamp.panda))
+    assert res.solved and res.edges_checked > 0 and len(res.path) >= 3
+    rid = oracle.robot("panda")
+    for a, b in zip(res.path[:-1], res.path[1:]):
+        assert oracle.validate_motion(rid, oenv, a, b)
+    better = fcit(vamp.panda, CAGE_START, CAGE_GOAL, env,
+                  FCITSettings(batch_size=400, max_samples=2400, optimize=True, max_iterations=8), Halton(vamp.panda))
+    assert better.solved and better.cost <= res.cost + 1e-6
+    for a, b in zip(better.path[:-1], better.path[1:]):
+        assert oracle.validate_motion(rid, oenv, a, b)
+    # a blocked goal is reported as unsolved, not as an exception
+    blocked = vamp.Environment()
+    blocked.add_sphere(vamp.Sphere([0.3, 0.0, 0.5], 0.6))
+    assert not fcit(vamp.panda, CAGE_START, CAGE_GOAL, blocked, FCITSettings(max_iterations=2)).solved
+
+
+@pytest.mark.gpu
 def test_batched_roadmap_edges_match_oracle(vamp, oracle):
     from vamp_mvt_amd.planning import Halton, build_roadmap
 

@@ -10,6 +10,8 @@ logic needed to drive the GPU path the way those planners do:
                         ingredients as rrtc.hh (two balanced trees, `range`-limited extension, connect loop), every
                         validity question answered by `validate_motion_batch` — extension and connect candidates of
                         one iteration are checked together;
+  * `fcit`              the batch form of the FCIT* loop (fcit.hh:137-349): lazy A* over the complete graph of the valid
+                        samples, the unknown edges of each candidate path validated together;
   * `build_roadmap`     the batched form of PRM's inner loops (prm.hh:109-189, roadmap construction :250-266):
                         validate all samples at once, then all k-nearest candidate edges at once, then connect
                         components / search on the host.
@@ -90,6 +92,9 @@ class PlanningResult:
     iterations: int = 0
     size: list = field(default_factory=list)
     validity_calls: int = 0
+    cost: float = float("inf")
+    edges_checked: int = 0
+    samples_drawn: int = 0
 
     @property
     def solved(self):
@@ -244,3 +249,98 @@ def build_roadmap(robot, environment, n_samples=2048, k=8, sampler: Halton | Non
     cand = np.array(sorted(pairs), np.int64)
     ok = robot.validate_motion_batch(v[cand[:, 0]], v[cand[:, 1]], environment)
     return Roadmap(v, cand[ok], len(cand), len(samples))
+
+
+@dataclass
+class FCITSettings:
+    """the knobs of planning/fcit.hh that matter for a batch driver"""
+    batch_size: int = 1000
+    max_samples: int = 20000
+    max_iterations: int = 64
+    optimize: bool = False  # keep adding batches after the first solution (prune with the current cost)
+
+
+def fcit(robot, start, goal, environment, settings: FCITSettings | None = None, sampler: Halton | None = None):
+    """Batch form of the FCIT* loop (planning/fcit.hh:137-349): sample a batch, keep the valid samples
+    (`validate_batch`), search the COMPLETE graph over all samples with A* (straight-line heuristic) treating
+    unchecked edges as free, then check the unknown edges of the candidate path together (`validate_motion_batch`),
+    delete the invalid ones and search again; add another batch when no path remains.  With `optimize`, later
+    batches only keep samples inside the current solution's ellipse (the informed set).  Every collision question
+    goes through the batched API; the reference asks the same questions one edge at a time (fcit.hh:238,333)."""
+    s = settings or FCITSettings()
+    rng = sampler or Halton(robot)
+    start, goal = np.asarray(start, np.float32), np.asarray(goal, np.float32)
+    res = PlanningResult()
+    if not robot.validate_batch(np.stack([start, goal]), environment).all():
+        return res
+    verts = np.stack([start, goal])
+    state = {}  # (i, j), i < j -> True valid / False invalid; absent = unchecked
+    best_cost, best_path = np.inf, None
+    drawn = checked = 0
+
+    def key(a, b):
+        return (a, b) if a < b else (b, a)
+
+    def astar():
+        n = len(verts)
+        h = np.linalg.norm(verts - verts[1], axis=1)
+        g = np.full(n, np.inf)
+        g[0] = 0.0
+        parent = np.full(n, -1)
+        closed = np.zeros(n, bool)
+        pq = [(float(h[0]), 0)]
+        while pq:
+            _, u = heapq.heappop(pq)
+            if closed[u]:
+                continue
+            closed[u] = True
+            if u == 1:
+                path = [1]
+                while path[-1] != 0:
+                    path.append(int(parent[path[-1]]))
+                return path[::-1], float(g[1])
+            d = np.linalg.norm(verts - verts[u], axis=1)
+            cand = np.flatnonzero(~closed & (g[u] + d + h < best_cost))
+            for v in cand:
+                if state.get(key(u, int(v))) is False:
+                    continue
+                ng = g[u] + d[v]
+                if ng < g[v]:
+                    g[v], parent[v] = ng, u
+                    heapq.heappush(pq, (float(ng + h[v]), int(v)))
+        return None, np.inf
+
+    for it in range(s.max_iterations):
+        res.iterations = it + 1
+        while True:
+            path, cost = astar()
+            if path is None:
+                break
+            unknown = [key(a, b) for a, b in zip(path[:-1], path[1:]) if key(a, b) not in state]
+            if not unknown:
+                if cost < best_cost:
+                    best_cost, best_path = cost, path
+                break
+            e = np.array(unknown, np.int64)
+            ok = robot.validate_motion_batch(verts[e[:, 0]], verts[e[:, 1]], environment)
+            checked += len(e)
+            for k, v in zip(unknown, ok):
+                state[k] = bool(v)
+        if best_path is not None and not s.optimize:
+            break
+        if drawn >= s.max_samples:
+            break
+        batch = rng.batch(s.batch_size)
+        drawn += len(batch)
+        keep = robot.validate_batch(batch, environment)
+        new = batch[keep]
+        if np.isfinite(best_cost):  # informed set: |x - start| + |x - goal| < current cost
+            new = new[np.linalg.norm(new - start, axis=1) + np.linalg.norm(new - goal, axis=1) < best_cost]
+        verts = np.vstack([verts, new])
+    if best_path is not None:
+        res.path = verts[best_path]
+        res.cost = best_cost
+    res.size = len(verts)
+    res.edges_checked = checked
+    res.samples_drawn = drawn
+    return res
