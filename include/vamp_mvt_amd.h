@@ -153,6 +153,20 @@ int vmv_validate_batch_self(int robot, const float *d_q, size_t n, uint64_t *d_b
 int vmv_validate_motion_batch(int robot, const vmv_env *env, const float *d_start, const float *d_goal, size_t n,
                               uint64_t *d_bits, void *stream);
 
+/* <robot>.debug(q, env) — robot_helper.hh:249-253 -> Robot::fkcc_debug: per fine sphere the environment objects it
+ * collides with (sphere_environment_get_collisions, collision/validity.hh:161-256: the five sorted primitive lists with
+ * their early break, then the heightfields; no point clouds), and the fine sphere pairs of the self-collision groups
+ * that overlap (all pairs, no bounding gates).  Host buffers.  env_words: [n][n_spheres][9]; words 0..7 hold 32
+ * sorted-list positions each, the lists back to back (vmv_env_report_layout gives each list's first word), word 8 the
+ * heightfields.  pair_words: [n][ceil(n_pairs / 32)], bit p = pair p of vmv_robot_self_pairs.  Environments whose
+ * lists need more than 8 words: VMV_ERR_CAPACITY. */
+int vmv_contacts_batch_host(int robot, const vmv_env *env, const float *q, size_t n, uint32_t *env_words,
+                            uint32_t *pair_words);
+/* first word of each sorted list in the report: spheres, capsules, z_capsules, cuboids, z_cuboids */
+int vmv_env_report_layout(const vmv_env *env, uint32_t *first_word5);
+/* the fine pairs the report covers: n_pairs, and (a, b) sphere indices into pairs2 (may be NULL) */
+int vmv_robot_self_pairs(int robot, size_t *n_pairs, uint16_t *pairs2);
+
 /* host-buffer variants (copies included; the PCIe-inclusive path) */
 int vmv_fk_batch_host(int robot, const float *q, size_t n, float *out);
 int vmv_eefk_batch_host(int robot, const float *q, size_t n, float *out);

@@ -114,6 +114,44 @@ def test_attachment_changes_answers_and_detach_restores_them(vamp, oracle, name)
     assert (without & ~with_att).sum() > 0 and (with_att & ~without).sum() == 0  # the attachment only removes validity
 
 
+@pytest.mark.parametrize("name", ["panda", "fetch"])
+def test_contact_report_matches_oracle_predicates(vamp, oracle, name):
+    """<robot>.debug (Robot::fkcc_debug): per-sphere object lists = the oracle's exact predicate against each object on
+    its own, self pairs = overlapping fine pairs; consistent with validate()."""
+    import ctypes
+    env, oenv = make_env("mixed", oracle, name)
+    tables = env.host_tables()
+    rid, q = uniform_configs(oracle, name, 40, seed=33)
+    robot = getattr(vamp, name)
+    f = ctypes.POINTER(ctypes.c_float)
+    singles = {}
+    for lst, adder in (("spheres", lambda e, p: e.add_sphere(*[float(v) for v in p[:4]])),
+                       ("capsules", lambda e, p: e.add_capsule(p[:8])), ("z_capsules", lambda e, p: e.add_capsule(p[:8])),
+                       ("cuboids", lambda e, p: e.add_cuboid(p[:15])), ("z_cuboids", lambda e, p: e.add_cuboid(p[:15]))):
+        for i, p in enumerate(tables[lst]):
+            e = oracle.env()
+            adder(e, np.ascontiguousarray(p, np.float32))
+            singles[(lst, i)] = e
+    any_env = any_self = 0
+    for c in q:
+        per_sphere, pairs = robot.debug(c, env)
+        spheres = robot.fk_batch(c[None, :])[0]
+        assert len(per_sphere) == robot.n_spheres()
+        for s, hits in enumerate(per_sphere):
+            want = [k for k, e in singles.items()
+                    if oracle.L.vo_sphere_environment_in_collision(e.h, np.ascontiguousarray(spheres[s, :3]).ctypes.data_as(f),
+                                                                   ctypes.c_float(float(spheres[s, 3])))]
+            assert sorted(hits) == sorted(want)
+            any_env += len(hits)
+        d = np.linalg.norm(spheres[:, None, :3] - spheres[None, :, :3], axis=2)
+        for a, b in pairs:
+            assert d[a, b] < spheres[a, 3] + spheres[b, 3] + 1e-6
+        any_self += len(pairs)
+        if robot.validate(c, env):
+            assert not pairs and not any(per_sphere)
+    assert any_env > 0 and any_self > 0
+
+
 def test_reference_known_answers_on_gpu(vamp, oracle, golden_dir):
     """The reference's own known answers, computed by the HIP path."""
     k = json.load(open(os.path.join(golden_dir, "known_answers.json")))

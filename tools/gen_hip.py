@@ -630,6 +630,13 @@ def emit_robot(m):
     L.append("    }")
     L.append("")
 
+    # ---- fine pair table (contact report) ---------------------------------------------------------------------
+    pairs = [p for sg in m["self_groups"] for p in sg["pairs"]]
+    L.append(f"    constexpr int kNSelfPairs = {len(pairs)};  // Robot::fkcc_debug tests every fine pair, without the gates")
+    L.append(f"    __constant__ unsigned short kSelfPairs[{max(len(pairs), 1)}][2] = {{" +
+             ", ".join("{%d, %d}" % (a, b) for a, b in pairs) + "};")
+    L.append("")
+
     # ---- sphere_fk ----------------------------------------------------------------------------------------
     L.append("    // Robot::sphere_fk (reference robots/%s.hh): out[s] = (x, y, z, r) of the fine spheres." % n)
     L.append("    __device__ __forceinline__ void sphere_fk(const float (&q)[kDim], float4 *out)")
@@ -650,6 +657,7 @@ def emit_robot(m):
     L.append(f"    static constexpr int kSlabSpheres = {n}::kSlabSpheres;")
     L.append(f"    static constexpr int kNRadii = {n}::kNRadii;")
     L.append(f"    static constexpr int kNStaticLinks = {n}::kNStaticLinks;")
+    L.append(f"    static constexpr int kNSelfPairs = {n}::kNSelfPairs;")
     L.append("    static __device__ __forceinline__ bool static_env_hit(const vmv::EnvView &E)")
     L.append("    {")
     L.append(f"        return {n}::static_env_hit(E);")
@@ -704,6 +712,10 @@ def main(models):
                 '#include "../vmv_robot_tu.inc"', ""]))
     # host-side robot table
     host = ["// GENERATED by tools/gen_hip.py - do not edit.", "#pragma once", ""]
+    for m in models:
+        pairs = [p for sg in m["self_groups"] for p in sg["pairs"]]
+        host.append(f"static const uint16_t kSelfPairs_{m['name']}[{max(len(pairs), 1)}][2] = {{" +
+                    ", ".join("{%d, %d}" % (a, b) for a, b in pairs) + "};")
     host.append("static const vmv_robot_info kRobots[] = {")
     for m in models:
         lo = ", ".join(flit(v) for v in m["lower"] + [0.0] * (16 - m["dimension"]))
@@ -714,7 +726,8 @@ def main(models):
         gr = ", ".join(flit(v) for v in grid_classes(m)[0])
         host.append(f'    {{"{m["name"]}", {m["dimension"]}, {m["n_spheres"]}, {m["resolution"]}, '
                     f'{flit(m["min_radius"])}, {flit(m["max_radius"])}, {flit(max_bound)}, {{{gr}}}, {{{lo}}}, {{{sp}}}, {{{ds}}}, '
-                    f'"{m["end_effector"]}", {{{jn}}}}},')
+                    f'"{m["end_effector"]}", {{{jn}}}, {sum(len(sg["pairs"]) for sg in m["self_groups"])}, '
+                    f'kSelfPairs_{m["name"]}}},')
     host.append("};")
     host.append(f"static const int kNumRobots = {len(models)};")
     with open(os.path.join(d, "robots_host.inc"), "w") as f:

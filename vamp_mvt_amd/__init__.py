@@ -477,6 +477,42 @@ class _Robot(types.ModuleType):
         a, b = _f32(start, (self._dim,)), _f32(goal, (self._dim,))
         return bool(self.validate_motion_batch(a[None, :], b[None, :], environment)[0])
 
+    def debug(self, configuration, environment: Environment | None = None):
+        """<robot>.debug(q, env) — robot_helper.hh:249-253 (Robot::fkcc_debug): (per fine sphere the objects it collides
+        with, the fine sphere pairs of the self-collision groups that overlap).  Objects are reported as
+        (list, position) = position in the environment's sorted "spheres" / "capsules" / "z_capsules" / "cuboids" /
+        "z_cuboids" tables (Environment.host_tables()) or ("heightfield", index) — the reference reports `name`s, which
+        this environment does not keep."""
+        q = _f32(configuration, (self._dim,))[None, :]
+        h = self._env(environment)
+        ns = self.n_spheres()
+        words = np.zeros((1, ns, 9), np.uint32)
+        npairs = ctypes.c_size_t(0)
+        check(lib.vmv_robot_self_pairs(self._id, ctypes.byref(npairs), None), "vmv_robot_self_pairs")
+        pairs = np.zeros((max(npairs.value, 1), 2), np.uint16)
+        check(lib.vmv_robot_self_pairs(self._id, ctypes.byref(npairs), pairs.ctypes.data_as(ctypes.POINTER(ctypes.c_uint16))),
+              "vmv_robot_self_pairs")
+        pw = np.zeros((1, max((npairs.value + 31) // 32, 1)), np.uint32)
+        check(lib.vmv_contacts_batch_host(self._id, h, _fp(q), 1, words.ctypes.data_as(_lib.c_u32_p),
+                                          pw.ctypes.data_as(_lib.c_u32_p)), "vmv_contacts_batch_host")
+        base = np.zeros(5, np.uint32)
+        check(lib.vmv_env_report_layout(h, base.ctypes.data_as(_lib.c_u32_p)), "vmv_env_report_layout")
+        counts = (ctypes.c_size_t * 6)()
+        check(lib.vmv_env_counts(h, counts), "vmv_env_counts")
+        names = ("spheres", "capsules", "z_capsules", "cuboids", "z_cuboids")
+        per_sphere = []
+        for s in range(ns):
+            hits = []
+            for li, name in enumerate(names):
+                for i in range(counts[li]):
+                    if (int(words[0, s, int(base[li]) + i // 32]) >> (i % 32)) & 1:
+                        hits.append((name, i))
+            hits += [("heightfield", i) for i in range(4) if (int(words[0, s, 8]) >> i) & 1]
+            per_sphere.append(hits)
+        hit_pairs = [(int(pairs[p, 0]), int(pairs[p, 1])) for p in range(npairs.value)
+                     if (int(pw[0, p // 32]) >> (p % 32)) & 1]
+        return per_sphere, hit_pairs
+
     def eefk(self, configuration):
         """<robot>.eefk(q) -> 4 x 4 end-effector frame — robot_helper.hh:279-282."""
         return self.eefk_batch(_f32(configuration, (self._dim,))[None, :])[0]

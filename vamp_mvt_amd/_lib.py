@@ -99,6 +99,9 @@ def _load():
         "vmv_validate_motion_batch": (I, [I, V, V, V, S, V, V]),
         "vmv_fk_batch_host": (I, [I, c_float_p, S, c_float_p]),
         "vmv_eefk_batch": (I, [I, V, S, V, V]),
+        "vmv_contacts_batch_host": (I, [I, V, c_float_p, S, c_u32_p, c_u32_p]),
+        "vmv_env_report_layout": (I, [V, c_u32_p]),
+        "vmv_robot_self_pairs": (I, [I, c_size_p, ctypes.POINTER(ctypes.c_uint16)]),
         "vmv_eefk_batch_host": (I, [I, c_float_p, S, c_float_p]),
         "vmv_env_attach": (I, [V, c_float_p, c_float_p, S]),
         "vmv_env_detach": (I, [V]),

@@ -33,6 +33,8 @@ struct vmv_robot_info
     float lower[16], span[16], descale[16];
     const char *end_effector;
     const char *joint_names[16];
+    int n_self_pairs;
+    const uint16_t (*self_pairs)[2];  // fine pairs of the self-collision groups, in group order
 };
 #include "gen/robots_host.inc"
 
@@ -204,6 +206,15 @@ namespace
     void sort_by_min_distance(std::vector<T> &v)
     {
         std::stable_sort(v.begin(), v.end(), [](const T &a, const T &b) { return a.min_d < b.min_d; });
+    }
+
+    // the getters return the lists as the kernels will see them: sorted by min_distance (stable), finalized or not
+    template <typename T>
+    std::vector<T> sorted_copy(const std::vector<T> &v)
+    {
+        std::vector<T> c(v);
+        sort_by_min_distance(c);
+        return c;
     }
 
     template <typename T>
@@ -654,15 +665,16 @@ extern "C"
     int vmv_env_get_spheres(const vmv_env *env, float *out, size_t cap, size_t *n)
     {
         if (!env || !n) return VMV_ERR_INVALID_ARGUMENT;
-        *n = env->spheres.size();
+        const auto v = sorted_copy(env->spheres);
+        *n = v.size();
         if (out)
-            for (size_t i = 0; i < std::min(cap, *n); ++i) std::memcpy(out + 5 * i, &env->spheres[i], 5 * sizeof(float));
+            for (size_t i = 0; i < std::min(cap, *n); ++i) std::memcpy(out + 5 * i, &v[i], 5 * sizeof(float));
         return VMV_OK;
     }
     int vmv_env_get_cuboids(const vmv_env *env, int z, float *out, size_t cap, size_t *n)
     {
         if (!env || !n) return VMV_ERR_INVALID_ARGUMENT;
-        const auto &v = z ? env->z_cuboids : env->cuboids;
+        const auto v = sorted_copy(z ? env->z_cuboids : env->cuboids);
         *n = v.size();
         if (out)
             for (size_t i = 0; i < std::min(cap, *n); ++i) std::memcpy(out + 16 * i, &v[i], 16 * sizeof(float));
@@ -671,7 +683,7 @@ extern "C"
     int vmv_env_get_capsules(const vmv_env *env, int z, float *out, size_t cap, size_t *n)
     {
         if (!env || !n) return VMV_ERR_INVALID_ARGUMENT;
-        const auto &v = z ? env->z_capsules : env->capsules;
+        const auto v = sorted_copy(z ? env->z_capsules : env->capsules);
         *n = v.size();
         if (out)
             for (size_t i = 0; i < std::min(cap, *n); ++i) std::memcpy(out + 9 * i, &v[i], 9 * sizeof(float));
@@ -818,6 +830,57 @@ extern "C"
         if (!d_q || !d_out) return VMV_ERR_INVALID_ARGUMENT;
         if (n == 0) return VMV_OK;
         return kLaunchers[robot]->fk(d_q, n, d_out, static_cast<hipStream_t>(stream));
+    }
+
+    int vmv_robot_self_pairs(int robot, size_t *n_pairs, uint16_t *pairs2)
+    {
+        if (!robot_ok(robot)) return VMV_ERR_UNKNOWN_ROBOT;
+        if (!n_pairs) return VMV_ERR_INVALID_ARGUMENT;
+        *n_pairs = (size_t) kRobots[robot].n_self_pairs;
+        if (pairs2) std::memcpy(pairs2, kRobots[robot].self_pairs, *n_pairs * 4);
+        return VMV_OK;
+    }
+    int vmv_env_report_layout(const vmv_env *env, uint32_t *w)
+    {
+        if (!env || !w) return VMV_ERR_INVALID_ARGUMENT;
+        if (!env->finalized) return VMV_ERR_NOT_FINALIZED;
+        const vmv::EnvDev &D = env->base;
+        uint32_t base = 0;
+        const uint32_t counts[5] = {D.n_sphere, D.n_capsule, D.n_zcapsule, D.n_cuboid, D.n_zcuboid};
+        for (int i = 0; i < 5; ++i)
+        {
+            w[i] = base;
+            base += (counts[i] + 31u) / 32u;
+        }
+        return VMV_OK;
+    }
+    int vmv_contacts_batch_host(int robot, const vmv_env *env, const float *q, size_t n, uint32_t *env_words,
+                                uint32_t *pair_words)
+    {
+        if (!robot_ok(robot)) return VMV_ERR_UNKNOWN_ROBOT;
+        if (!env || !q || !env_words || !pair_words) return VMV_ERR_INVALID_ARGUMENT;
+        if (!env->finalized) return VMV_ERR_NOT_FINALIZED;
+        if (n == 0) return VMV_OK;
+        int rc = require_device();
+        if (rc != VMV_OK) return rc;
+        if ((rc = ensure_robot(env, robot)) != VMV_OK) return rc;
+        const size_t ns = (size_t) kRobots[robot].n_spheres, npw = ((size_t) kLaunchers[robot]->n_self_pairs + 31) / 32;
+        const size_t qb = n * (size_t) kRobots[robot].dimension * 4, sb = n * ns * 16, eb = n * ns * (vmv::kReportWords + 1) * 4,
+                     pb = std::max<size_t>(n * npw * 4, 4);
+        char *d = nullptr;
+        VMV_HIP(hipMalloc((void **) &d, qb + sb + eb + pb + 1024));
+        float *dq = reinterpret_cast<float *>(d), *ds = reinterpret_cast<float *>(d + ((qb + 255) & ~size_t{255}));
+        uint32_t *de = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(ds) + ((sb + 255) & ~size_t{255}));
+        uint32_t *dp = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(de) + ((eb + 255) & ~size_t{255}));
+        rc = VMV_OK;
+        if (hipMemcpy(dq, q, qb, hipMemcpyHostToDevice) != hipSuccess || hipMemset(dp, 0, pb) != hipSuccess) rc = VMV_ERR_HIP;
+        if (rc == VMV_OK) rc = kLaunchers[robot]->fk(dq, n, ds, nullptr);
+        if (rc == VMV_OK) rc = kLaunchers[robot]->contacts(env->launch[robot], ds, n, de, dp, nullptr);
+        if (rc == VMV_OK && (hipMemcpy(env_words, de, eb, hipMemcpyDeviceToHost) != hipSuccess ||
+                             (npw && hipMemcpy(pair_words, dp, n * npw * 4, hipMemcpyDeviceToHost) != hipSuccess)))
+            rc = VMV_ERR_HIP;
+        (void) hipFree(d);
+        return rc;
     }
 
     int vmv_eefk_batch(int robot, const float *d_q, size_t n, float *d_out, void *stream)

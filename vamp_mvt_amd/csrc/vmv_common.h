@@ -34,6 +34,10 @@ namespace vmv
         // against the environment and stores the answer in d_env->static_hit (synchronous)
         int (*prepare)(const EnvLaunch &, EnvDev *d_env);
         int (*eefk)(const float *d_q, size_t n, float *d_out16, hipStream_t);  // 4 x 4 row-major frames
+        // contact report (Robot::fkcc_debug) from the fine spheres of launch fk
+        int (*contacts)(const EnvLaunch &, const float *d_spheres, size_t n, uint32_t *d_env_words, uint32_t *d_pair_words,
+                        hipStream_t);
+        int n_self_pairs;
     };
 
     extern const RobotLaunchers kPandaLaunchers, kUr5Launchers, kFetchLaunchers, kBaxterLaunchers;

@@ -728,6 +728,46 @@ namespace vmv
 #undef D
     }
 
+    // Contact report (Robot::fkcc_debug -> sphere_environment_get_collisions, collision/validity.hh:161-256): which
+    // primitives one sphere collides with, as bits in the candidate-word layout (wbase_* per list, 32 primitives per
+    // word, sorted-list positions) plus one word for the heightfields.  Replicated-configuration semantics (G = 1).
+    template <int T>
+    __device__ __forceinline__ void list_hit_words(const EnvView &E, const uint32_t n, const uint32_t off, const uint32_t wbase,
+                                                   float x, float y, float z, float r, float rsq, float ext, uint32_t *words)
+    {
+        constexpr int REC = PrimTraits<T>::rec;
+        for (uint32_t i = 0; i < n; ++i)
+        {
+            float v, md, reach;
+            prim_eval<T>(E.lds + off + i * REC, x, y, z, r, rsq, v, md, reach);
+            if (!neg(md - ext)) break;  // sorted: nothing behind it can be reached either (validity.hh:179-183)
+            if (neg(v)) words[wbase + (i >> 5)] |= 1u << (i & 31u);
+        }
+    }
+    constexpr int kReportWords = 8;  // 32-primitive words of a contact report (its own layout: lists back to back)
+    __device__ __forceinline__ void sphere_hit_words(const EnvView &E, float x, float y, float z, float r,
+                                                     uint32_t (&words)[kReportWords + 1])
+    {
+        const env_cptr Dp = E.dev;
+#define D (*Dp)
+        const float ext = sqrtf(dot3(x, y, z, x, y, z)) + r, rsq = r * r;
+#pragma unroll
+        for (int w = 0; w <= kReportWords; ++w) words[w] = 0u;
+        uint32_t base = 0;
+        list_hit_words<kSphere>(E, D.n_sphere, D.off_sphere, base, x, y, z, r, rsq, ext, words);
+        base += (D.n_sphere + 31u) / 32u;
+        list_hit_words<kCapsule>(E, D.n_capsule, D.off_capsule, base, x, y, z, r, rsq, ext, words);
+        base += (D.n_capsule + 31u) / 32u;
+        list_hit_words<kZCapsule>(E, D.n_zcapsule, D.off_zcapsule, base, x, y, z, r, rsq, ext, words);
+        base += (D.n_zcapsule + 31u) / 32u;
+        list_hit_words<kCuboid>(E, D.n_cuboid, D.off_cuboid, base, x, y, z, r, rsq, ext, words);
+        base += (D.n_cuboid + 31u) / 32u;
+        list_hit_words<kZCuboid>(E, D.n_zcuboid, D.off_zcuboid, base, x, y, z, r, rsq, ext, words);
+        for (uint32_t hi = 0; hi < D.n_heightfield; ++hi)
+            if (heightfield_collides(Dp, hi, x, y, z, r)) words[kReportWords] |= 1u << hi;
+#undef D
+    }
+
     // One sorted list in the gate pass, driven by the broad-phase grid: this lane evaluates the reference's exact
     // predicates on the candidates of its own cell only, and records the fine-phase candidates (kCandidateMargin)
     // among them.  Lanes walk their own candidate bits; the loop runs until the busiest lane is done.
