@@ -499,7 +499,11 @@ extern "C"
         vmv::EnvDev &D = D_base;
         D.n_sphere = (uint32_t) env->spheres.size();
         D.off_sphere = (uint32_t) block.size();
-        for (const auto &s : env->spheres) block.insert(block.end(), {s.x, s.y, s.z, s.r, s.min_d, 0.f, 0.f, 0.f});
+        for (const auto &s : env->spheres)
+        {
+            block.insert(block.end(), {s.x, s.y, s.z, s.r, s.min_d});
+            block.insert(block.end(), (size_t) vmv::kSphereRec - 5, 0.f);
+        }
         D.n_capsule = (uint32_t) env->capsules.size();
         D.off_capsule = (uint32_t) block.size();
         for (const auto &c : env->capsules)

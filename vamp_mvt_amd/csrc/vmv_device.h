@@ -773,15 +773,17 @@ namespace vmv
     // among them.  Lanes walk their own candidate bits; the loop runs until the busiest lane is done.
     template <int T>
     __device__ __forceinline__ void list_grid(const EnvView &E, const uint32_t n, const uint32_t off, const uint32_t wbase,
-                                              const gu_cptr cell, float x, float y, float z, float r, float rsq, float ext,
-                                              bool inside, bool &hit, lds_u32 *mask_lane)
+                                              const uint32_t (&cw)[kMaskWords], float x, float y, float z, float r,
+                                              float rsq, float ext, bool &hit, lds_u32 *mask_lane)
     {
         if (n == 0) return;
         constexpr int REC = PrimTraits<T>::rec;
         const uint32_t words = (n + 31) / 32;
         for (uint32_t w = 0; w < words; ++w)
         {
-            uint32_t m = inside ? cell[wbase + w] : 0u;
+            // (wave-uniform index into the preloaded words: selects, not a scratch array)
+            const uint32_t k = wbase + w;
+            uint32_t m = (k == 0u) ? cw[0] : (k == 1u) ? cw[1] : (k == 2u) ? cw[2] : cw[3];
             uint32_t fine = 0u;
             while (wave_any(m != 0u))
             {
@@ -789,7 +791,13 @@ namespace vmv
                 {
                     const uint32_t bit = (uint32_t) __ffs((int) m) - 1u;
                     m &= m - 1u;
-                    lds_cptr rec = E.lds + off + (w * 32u + bit) * REC;
+                    if (VMV_ABLATE_ENV == 4)  // measurement aid: the walk without evaluating anything
+                    {
+                        fine |= 1u << bit;
+                        continue;
+                    }
+                    // measurement aid 5: every lane reads record 0 (no gather: broadcast reads)
+                    lds_cptr rec = E.lds + off + ((VMV_ABLATE_ENV == 5) ? 0u : (w * 32u + bit) * REC);
                     float v, md, reach;
                     prim_eval<T>(rec, x, y, z, r, rsq, v, md, reach);
                     hit |= neg(md - ext) && neg(v);
@@ -797,7 +805,7 @@ namespace vmv
                     fine |= (v < tau) ? (1u << bit) : 0u;
                 }
             }
-            mask_lane[(wbase + w) * kWave] = fine;
+            mask_lane[(wbase + w) * kWave] = (VMV_ABLATE_ENV == 4 || VMV_ABLATE_ENV == 5) ? 0u : fine;
         }
     }
 
@@ -820,12 +828,19 @@ namespace vmv
         const uint32_t ix = inside ? (uint32_t) fx : 0u, iy = inside ? (uint32_t) fy : 0u, iz = inside ? (uint32_t) fz : 0u;
         const gu_cptr cell = (gu_cptr) Gd->cells + ((size_t) (ix * d1 + iy) * d2 + iz) * D.grid_words;
         bool hit = false;
-        list_grid<kSphere>(E, D.n_sphere, D.off_sphere, D.wbase_sphere, cell, x, y, z, r, rsq, ext, inside, hit, mask_lane);
-        list_grid<kCapsule>(E, D.n_capsule, D.off_capsule, D.wbase_capsule, cell, x, y, z, r, rsq, ext, inside, hit, mask_lane);
-        list_grid<kZCapsule>(E, D.n_zcapsule, D.off_zcapsule, D.wbase_zcapsule, cell, x, y, z, r, rsq, ext, inside, hit,
-                             mask_lane);
-        list_grid<kCuboid>(E, D.n_cuboid, D.off_cuboid, D.wbase_cuboid, cell, x, y, z, r, rsq, ext, inside, hit, mask_lane);
-        list_grid<kZCuboid>(E, D.n_zcuboid, D.off_zcuboid, D.wbase_zcuboid, cell, x, y, z, r, rsq, ext, inside, hit, mask_lane);
+        // all candidate words of the cell at once (independent loads, one memory latency per gate instead of one per
+        // list and word: the walks below were waiting on these loads, not on arithmetic)
+        static_assert(kMaskWords == 4, "list_grid selects among four preloaded words");
+        uint32_t cw[kMaskWords];
+        const uint32_t gw = D.grid_words;
+#pragma unroll
+        for (int w = 0; w < kMaskWords; ++w) cw[w] = (inside && (uint32_t) w < gw) ? cell[w] : 0u;
+        if (VMV_ABLATE_ENV == 3) return inside && cw[0] == 0x12345u;  // measurement aid: gate overhead without the walks
+        list_grid<kSphere>(E, D.n_sphere, D.off_sphere, D.wbase_sphere, cw, x, y, z, r, rsq, ext, hit, mask_lane);
+        list_grid<kCapsule>(E, D.n_capsule, D.off_capsule, D.wbase_capsule, cw, x, y, z, r, rsq, ext, hit, mask_lane);
+        list_grid<kZCapsule>(E, D.n_zcapsule, D.off_zcapsule, D.wbase_zcapsule, cw, x, y, z, r, rsq, ext, hit, mask_lane);
+        list_grid<kCuboid>(E, D.n_cuboid, D.off_cuboid, D.wbase_cuboid, cw, x, y, z, r, rsq, ext, hit, mask_lane);
+        list_grid<kZCuboid>(E, D.n_zcuboid, D.off_zcuboid, D.wbase_zcuboid, cw, x, y, z, r, rsq, ext, hit, mask_lane);
         hit = hit && active;
         for (uint32_t hi = 0; hi < D.n_heightfield; ++hi)  // validity.hh:131-137
         {

@@ -17,6 +17,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <vector>
 
 namespace vmv
@@ -140,7 +141,11 @@ namespace vmv
             if (!(hi[k] - lo[k] < 1e4)) return false;  // absurd extents: no grid, full loops
             vol *= hi[k] - lo[k];
         }
-        double h = std::max(0.06, std::cbrt(vol / 24000.0));
+        // cell edge: at least kMinCell, and no more than kMaxCells cells (VMV_GRID_CELLS / VMV_GRID_MIN_CELL: tuning knobs)
+        double max_cells = 24000.0, min_cell = 0.06;
+        if (const char *e = std::getenv("VMV_GRID_CELLS")) max_cells = std::max(1000.0, std::atof(e));
+        if (const char *e = std::getenv("VMV_GRID_MIN_CELL")) min_cell = std::max(0.005, std::atof(e));
+        double h = std::max(min_cell, std::cbrt(vol / max_cells));
         for (int k = 0; k < 3; ++k)
         {
             out.dims[k] = (uint32_t) std::max(1.0, std::ceil((hi[k] - lo[k]) / h));
