@@ -205,6 +205,18 @@ def test_large_primitive_lists_and_capacity(vamp, oracle):
     assert ei.value.status == 4  # VMV_ERR_CAPACITY
 
 
+@pytest.mark.parametrize("name", ["panda", "baxter"])
+def test_counted_loop_gate_without_the_grid(vamp, oracle, name, monkeypatch):
+    """VMV_NO_GRID=1: the bounding-sphere pass falls back to the counted sorted loops (the path environments take whose
+    grid cannot be built); same answers."""
+    monkeypatch.setenv("VMV_NO_GRID", "1")
+    env, oenv = make_env("shell64", oracle, name, seed=3)  # a fresh environment: the robot part is built on first use
+    rid, q = uniform_configs(oracle, name, 6000, seed=8)
+    assert np.array_equal(getattr(vamp, name).validate_batch(q, env), oracle.validate_batch(rid, oenv, q, threads=8))
+    a, b = q[:400], q[400:800]
+    assert np.array_equal(getattr(vamp, name).validate_motion_batch(a, b, env), oracle.validate_motion_batch(rid, oenv, a, b))
+
+
 def test_environment_rebuild_after_mutation(vamp, oracle):
     env, oenv = make_env("cage", oracle)
     rid, q = uniform_configs(oracle, "panda", 4000, seed=2)
