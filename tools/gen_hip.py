@@ -448,22 +448,35 @@ def emit_robot(m):
                     em.lines.append(f"{J}if (vmv::wave_any(" + " || ".join(gate_names[gi] for gi in batch_groups) + f"))  // sparse groups, chunk {ci}")
                     em.lines.append(f"{J}{{")
                     K = J + "    "
+                    # entries are appended group by group, so entry counts are also item boundaries: the items are
+                    # dealt GROUP-MAJOR (all items of group 0, then group 1, ...) and a round of 64 items touches one or
+                    # two groups instead of all of them - only those run their A loops
                     em.lines.append(f"{K}int k = 0;")
                     for li, gi in enumerate(batch_groups):
+                        em.lines.append(f"{K}const int kk{li} = k;")
                         em.lines.append(f"{K}k = vmv::deal_append(list2, k, {gate_names[gi]}, {li}u << 6);  // {groups[gi]['a']}")
+                    em.lines.append(f"{K}const int kk{len(batch_groups)} = k;")
                     em.lines.append(f"{K}vmv::wave_lds_sync();")
                     em.lines.append(f"{K}const int items = k * {len(ch)};")
-                    em.lines.append(f"{K}const float inv_k = 1.0f / (float) k;")
+                    for li in range(len(batch_groups)):
+                        em.lines.append(f"{K}const int n{li} = kk{li + 1} - kk{li};")
+                        em.lines.append(f"{K}const float inv{li} = 1.0f / (float) (n{li} > 0 ? n{li} : 1);")
                     em.lines.append(f"{K}for (int base = 0; base < items; base += vmv::kWave)")
                     em.lines.append(f"{K}{{")
                     K2 = K + "    "
                     em.lines.append(f"{K2}const int i = base + (int) lane;")
                     em.lines.append(f"{K2}const bool act = i < items;")
-                    em.lines.append(f"{K2}const int t = act ? (int) (((float) i + 0.5f) * inv_k) : 0;")
-                    em.lines.append(f"{K2}const int j = act ? (i - t * k) : 0;")
+                    em.lines.append(f"{K2}int first = 0, n = n0;")
+                    em.lines.append(f"{K2}float inv = inv0;")
+                    em.lines.append(f"{K2}unsigned grp = 0u;")
+                    for li in range(1, len(batch_groups)):
+                        em.lines.append(f"{K2}if (i >= kk{li} * {len(ch)}) first = kk{li}, n = n{li}, inv = inv{li}, grp = {li}u;")
+                    em.lines.append(f"{K2}const int local = i - first * {len(ch)};")
+                    em.lines.append(f"{K2}const int t = act ? (int) (((float) local + 0.5f) * inv) : 0;")
+                    em.lines.append(f"{K2}const int j = act ? first + (local - t * n) : 0;")
                     em.lines.append(f"{K2}const unsigned e = list2[j];")
                     em.lines.append(f"{K2}const unsigned src = e & 63u;")
-                    em.lines.append(f"{K2}const unsigned grp = act ? (e >> 6) : ~0u;")
+                    em.lines.append(f"{K2}grp = act ? grp : ~0u;")
                     b_fetch(K2, off)
                     em.lines.append(f"{K2}bool h = false;")
                     for li, gi in enumerate(batch_groups):
