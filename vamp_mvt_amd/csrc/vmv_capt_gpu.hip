@@ -397,9 +397,18 @@ int build_capt_device(const float *xyz_host, size_t n, float r_min, float r_max,
         b_scalars, b_out, b_aabbs, b_nvec;
     VMV_C(b_in.reserve(n * 12));
     VMV_C(hipMemcpy(b_in.p, xyz_host, n * 12, hipMemcpyHostToDevice));
-    hipEvent_t e0, e1;
-    VMV_C(hipEventCreate(&e0));
-    VMV_C(hipEventCreate(&e1));
+    struct Events  // destroyed on every exit path
+    {
+        hipEvent_t a = nullptr, b = nullptr;
+        ~Events()
+        {
+            if (a) (void) hipEventDestroy(a);
+            if (b) (void) hipEventDestroy(b);
+        }
+    } ev;
+    VMV_C(hipEventCreate(&ev.a));
+    VMV_C(hipEventCreate(&ev.b));
+    hipEvent_t e0 = ev.a, e1 = ev.b;
     VMV_C(hipEventRecord(e0, s));
 
     VMV_C(b_pts.reserve((size_t) leaves * 12));
@@ -481,6 +490,9 @@ int build_capt_device(const float *xyz_host, size_t n, float r_min, float r_max,
         uint32_t next_total = 0;
         VMV_C(hipMemcpyAsync(&next_total, size_scan + 2 * n_nodes, 4, hipMemcpyDeviceToHost, s));
         VMV_C(hipStreamSynchronize(s));
+        // list positions are 32-bit.  A level at most doubles the entries and adds one sibling half per node
+        // (<= leaves <= 2^24), so stopping at 2^30 entries keeps every later sum below 2^32.
+        if (next_total > (1u << 30)) return VMV_ERR_CAPACITY;
         VMV_C(b_ent[cur ^ 1].reserve(((size_t) next_total + 1) * 8));
         uint32_t *out_id = b_ent[cur ^ 1].as<uint32_t>(), *out_node = out_id + next_total;
         if (total)
@@ -524,8 +536,6 @@ int build_capt_device(const float *xyz_host, size_t n, float r_min, float r_max,
     float ms = 0.f;
     VMV_C(hipEventElapsedTime(&ms, e0, e1));
     if (device_ns) *device_ns = (uint64_t) ((double) ms * 1e6);
-    (void) hipEventDestroy(e0);
-    (void) hipEventDestroy(e1);
 
     // hand the result buffers over (the caller frees them); only the 24-byte top box is read back now
     uint32_t top[6];
