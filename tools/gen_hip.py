@@ -240,7 +240,7 @@ def emit_robot(m):
     L.append("    // Environment half of Robot::fkcc<rake> (reference robots/%s.hh `fkcc`, \"environment vs. robot" % n)
     L.append("    // collisions\"): true = some link group of this rake reports a collision.")
     L.append("    // `skip` (rake-uniform): this rake's answer is not needed; it only keeps the lanes converged.")
-    L.append("    template <int G>")
+    L.append("    template <int G, bool CLOUDS>")
     L.append("    __device__ __forceinline__ bool")
     L.append("    fkcc_env(const vmv::EnvView &E, const float (&q)[kDim], vmv::lds_ptr slab, const bool skip)")
     L.append("    {")
@@ -268,7 +268,7 @@ def emit_robot(m):
         for si, s in enumerate(chunks[0]):
             stage(1 + si, s, "        ")
         em.lines.append("        {")
-        em.lines.append(f"            const bool gate = vmv::env_gate<G, Tab>(E, slab, scratch, {radii_off[ln]}, {link_class[ln]}, !bad);")
+        em.lines.append(f"            const bool gate = vmv::env_gate<G, Tab, CLOUDS>(E, slab, scratch, {radii_off[ln]}, {link_class[ln]}, !bad);")
         em.lines.append("            if (VMV_ABLATE_ENV >= 1) bad |= gate;  // measurement aid: no fine phase (wrong answers)")
         em.lines.append("            else if (vmv::wave_any(gate))")
         em.lines.append("            {")
@@ -277,7 +277,7 @@ def emit_robot(m):
             if ci > 0:
                 for si, s in enumerate(ch):
                     stage(1 + si, s, "                ")
-            em.lines.append(f"                vmv::env_fine<G, Tab>(E, slab, scratch, {len(ch)}, {radii_off[ln] + 1 + done});")
+            em.lines.append(f"                vmv::env_fine<G, Tab, CLOUDS>(E, slab, scratch, {len(ch)}, {radii_off[ln] + 1 + done});")
             done += len(ch)
         em.lines.append("                bad |= gate && vmv::group_any<G>(vmv::env_flag(scratch));")
         em.lines.append("            }")
@@ -676,11 +676,11 @@ def emit_robot(m):
     L.append(f"        return {n}::static_env_hit(E);")
     L.append("    }")
     L.append(f"    static constexpr int kSelfBlocks = {SELF_BLOCKS.get(n, 2)};  // workgroups per CU the self-collision kernel is compiled for")
-    L.append("    template <int G>")
+    L.append("    template <int G, bool CLOUDS>")
     L.append("    static __device__ __forceinline__ bool")
     L.append("    fkcc_env(const vmv::EnvView &E, const float (&q)[kDim], vmv::lds_ptr slab, const bool skip)")
     L.append("    {")
-    L.append(f"        return {n}::fkcc_env<G>(E, q, slab, skip);")
+    L.append(f"        return {n}::fkcc_env<G, CLOUDS>(E, q, slab, skip);")
     L.append("    }")
     L.append("    template <int G>")
     L.append("    static __device__ __forceinline__ bool")

@@ -674,7 +674,9 @@ namespace vmv
     //    largest max_extent in the wave; each lane still applies its own break predicate.
     //    MODE 2 (fine): only the candidates the lane's bounding sphere recorded (see kCandidateMargin).
     //  * `active` only prunes work: inactive lanes do not extend the trip counts and report no hit.
-    template <int G, int MODE>
+    //  * CLOUDS = false compiles the heightfield / CAPT / MVT tail out: environments made of primitives only run
+    //    kernels without that code (and its registers; measured 6-8 % on the environment kernel).
+    template <int G, int MODE, bool CLOUDS = true>
     __device__ __forceinline__ bool
     env_hit(const EnvView &E, float x, float y, float z, float r, bool active, lds_u32 *mask)
     {
@@ -707,6 +709,7 @@ namespace vmv
                                          ext, ext_wave, hit, mask);
         }
         hit = hit && active;
+        if constexpr (!CLOUDS) return hit;
         for (uint32_t hi = 0; hi < D.n_heightfield; ++hi)  // validity.hh:131-137
         {
             if (!wave_any(active && !hit)) break;
@@ -810,7 +813,7 @@ namespace vmv
     }
 
     // Gate pass of one bounding sphere through the broad-phase grid (same answer as env_hit<G, 1>).
-    template <int G>
+    template <int G, bool CLOUDS = true>
     __device__ __forceinline__ bool
     env_hit_grid(const EnvView &E, const uint32_t cls, float x, float y, float z, float r, bool active, lds_u32 *mask_lane)
     {
@@ -842,6 +845,7 @@ namespace vmv
         list_grid<kCuboid>(E, D.n_cuboid, D.off_cuboid, D.wbase_cuboid, cw, x, y, z, r, rsq, ext, hit, mask_lane);
         list_grid<kZCuboid>(E, D.n_zcuboid, D.off_zcuboid, D.wbase_zcuboid, cw, x, y, z, r, rsq, ext, hit, mask_lane);
         hit = hit && active;
+        if constexpr (!CLOUDS) return hit;
         for (uint32_t hi = 0; hi < D.n_heightfield; ++hi)  // validity.hh:131-137
         {
             if (!wave_any(active && !hit)) break;
@@ -889,7 +893,7 @@ namespace vmv
     //              max_extent.  Hits are OR-ed back per configuration through LDS flags.
     //   env_flag   this lane's "some fine sphere of my configuration hit".
     // `active` (rake-uniform) only prunes work.  Tab::radius(i) reads the robot's __constant__ radius table.
-    template <int G, typename Tab>
+    template <int G, typename Tab, bool CLOUDS = true>
     __device__ __noinline__ bool
     env_gate(const EnvView E_, lds_cptr slab, lds_ptr scratch_, const int radius_index_, const int grid_class_,
              const bool active)
@@ -901,17 +905,17 @@ namespace vmv
         if (VMV_ABLATE_ENV >= 2) return slab[0] > 1e30f;  // measurement aid: FK only (keeps the FK results alive)
         bool own;
         if (E.dev->masked_fine && E.dev->grid[0].cells != nullptr)
-            own = env_hit_grid<G>(E, (uint32_t) uniform(grid_class_), slab[0], slab[kRow], slab[2 * kRow],
+            own = env_hit_grid<G, CLOUDS>(E, (uint32_t) uniform(grid_class_), slab[0], slab[kRow], slab[2 * kRow],
                                   Tab::radius(uniform(radius_index_)), active, mask_lane);
         else if (E.dev->masked_fine)
         {
 #pragma unroll
             for (int w = 0; w < kMaskWords; ++w) mask_lane[w * kWave] = 0u;
-            own = env_hit<G, 1>(E, slab[0], slab[kRow], slab[2 * kRow], Tab::radius(uniform(radius_index_)), active,
+            own = env_hit<G, 1, CLOUDS>(E, slab[0], slab[kRow], slab[2 * kRow], Tab::radius(uniform(radius_index_)), active,
                                 mask_lane);
         }
         else
-            own = env_hit<G, 0>(E, slab[0], slab[kRow], slab[2 * kRow], Tab::radius(uniform(radius_index_)), active,
+            own = env_hit<G, 0, CLOUDS>(E, slab[0], slab[kRow], slab[2 * kRow], Tab::radius(uniform(radius_index_)), active,
                                 nullptr);
         const bool gate = group_any<G>(own);
         const uint64_t mask = __ballot(gate);
@@ -937,7 +941,7 @@ namespace vmv
         return a;
     }
 
-    template <int G, typename Tab>
+    template <int G, typename Tab, bool CLOUDS = true>
     __device__ __noinline__ void
     env_fine(const EnvView E_, lds_cptr slab, lds_ptr scratch_, const int n_fine_, const int radii_offset_,
              const int full_ = 0 /* 1: no candidate words (spheres without a bounding-sphere pass: attachments) */)
@@ -965,10 +969,10 @@ namespace vmv
             lds_cptr p = wave_slab + 3 * (s + 1) * kRow + src;
             bool hit;
             if (masked)
-                hit = env_hit<G, 2>(E, p[0], p[kRow], p[2 * kRow], E.radii[radii_offset + s], act,
+                hit = env_hit<G, 2, CLOUDS>(E, p[0], p[kRow], p[2 * kRow], E.radii[radii_offset + s], act,
                                     list + 2 * kWave + 4 + src);
             else
-                hit = env_hit<G, 0>(E, p[0], p[kRow], p[2 * kRow], E.radii[radii_offset + s], act, nullptr);
+                hit = env_hit<G, 0, CLOUDS>(E, p[0], p[kRow], p[2 * kRow], E.radii[radii_offset + s], act, nullptr);
             if (hit) flags[src] = 1u;
         }
         wave_lds_sync();
