@@ -145,6 +145,8 @@ def gate_rates(m, n=4096, seed=0):
 
 
 SELF_DEAL_MAX_A = 40  # A-side spheres kept in registers for the re-dealt self-collision form
+ENV_CHUNK = {"panda": 5}   # fine spheres per slab chunk in the environment kernels (default CHUNK); a smaller slab
+ENV_BLOCKS = {"panda": 5}  # ... lets five workgroups (20 waves) share a CU's LDS where the registers allow it
 SELF_BLOCKS = {"panda": 3, "ur5": 3}  # workgroups per CU the self kernel is compiled for (512 / blocks VGPRs per lane)
 SELF_DENSE_RATE = 0.5   # groups whose bounding-pair gate fires for at least this share of uniform configurations ...
 SELF_DENSE_MIN_A = 3    # ... and whose A side is at least this large use the pre-test + compaction form
@@ -220,14 +222,17 @@ def emit_robot(m):
         radii_off[ln] = len(radii_tab)
         radii_tab += [radii[g["bound"]]] + [radii[s] for s in g["fine"]]
     max_group = max(len(g["fine"]) for g in m["env_groups"])
-    slab_spheres = 1 + min(CHUNK, max_group)
+    env_chunk = ENV_CHUNK.get(n, CHUNK)
+    slab_spheres = 1 + min(env_chunk, max_group)
+    self_slab_spheres = 1 + min(CHUNK, max_group)
 
     L.append(f"namespace {n}")
     L.append("{")
     L.append(f"    constexpr int kDim = {dim};")
     L.append(f"    constexpr int kNSpheres = {m['n_spheres']};")
     L.append(f"    constexpr int kResolution = {m['resolution']};")
-    L.append(f"    constexpr int kSlabSpheres = {slab_spheres};  // bounding sphere + one chunk of fine spheres")
+    L.append(f"    constexpr int kSlabSpheres = {slab_spheres};  // environment kernels: bounding sphere + one chunk of fine spheres")
+    L.append(f"    constexpr int kSelfSlabSpheres = {self_slab_spheres};  // self-collision kernels: one chunk of B spheres")
     L.append(f"    constexpr int kNRadii = {len(radii_tab)};")
     L.append(f"    __constant__ float kRadii[{len(radii_tab)}] = {{" + ", ".join(flit(v) for v in radii_tab) + "};")
     L.append("    struct Tab")
@@ -253,7 +258,7 @@ def emit_robot(m):
     for ln in links:
         g = env_by_link[ln]
         fine = g["fine"]
-        chunks = [fine[i:i + CHUNK] for i in range(0, len(fine), CHUNK)]
+        chunks = [fine[i:i + env_chunk] for i in range(0, len(fine), env_chunk)]
         if ln in static:
             em.lines.append(f"        // ---- {ln}: static, evaluated once per environment (static_env_hit)")
             continue
@@ -350,7 +355,7 @@ def emit_robot(m):
     L.append("        const unsigned lane = __lane_id();")
     L.append("        const vmv::lds_cptr wave_slab = vmv::uniform((vmv::lds_cptr) (slab - lane));")
     L.append("        const vmv::lds_cptr radii = vmv::uniform(radii_);")
-    L.append("        vmv::lds_u32 *const list = (vmv::lds_u32 *) (slab - lane + kSlabSpheres * 3 * vmv::kRow);")
+    L.append("        vmv::lds_u32 *const list = (vmv::lds_u32 *) (slab - lane + kSelfSlabSpheres * 3 * vmv::kRow);")
     L.append("        vmv::lds_u32 *const flags = list + vmv::kWave;")
     L.append("        vmv::lds_u32 *const cand = list + 2 * vmv::kWave + 4;  // A-side candidate word per owner lane")
     L.append(f"        vmv::lds_u32 *const list2 = cand + vmv::kWave;        // item lists: (owner lane | tag << 6), <= {max(CHUNK, SPARSE_BATCH)} * 64 entries")
@@ -668,6 +673,8 @@ def emit_robot(m):
     L.append(f"    static constexpr int kNSpheres = {n}::kNSpheres;")
     L.append(f"    static constexpr int kResolution = {n}::kResolution;")
     L.append(f"    static constexpr int kSlabSpheres = {n}::kSlabSpheres;")
+    L.append(f"    static constexpr int kSelfSlabSpheres = {n}::kSelfSlabSpheres;")
+    L.append(f"    static constexpr int kEnvBlocks = {ENV_BLOCKS.get(n, 4)};  // workgroups per CU the environment kernel is compiled for")
     L.append(f"    static constexpr int kNRadii = {n}::kNRadii;")
     L.append(f"    static constexpr int kNStaticLinks = {n}::kNStaticLinks;")
     L.append(f"    static constexpr int kNSelfPairs = {n}::kNSelfPairs;")
