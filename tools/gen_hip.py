@@ -147,12 +147,12 @@ def gate_rates(m, n=4096, seed=0):
 SELF_DEAL_MAX_A = 40  # A-side spheres kept in registers for the re-dealt self-collision form
 ENV_CHUNK = {"panda": 5}   # fine spheres per slab chunk in the environment kernels (default CHUNK); a smaller slab
 ENV_BLOCKS = {"panda": 5}  # ... lets five workgroups (20 waves) share a CU's LDS where the registers allow it
-SELF_BLOCKS = {"panda": 3, "ur5": 3}  # workgroups per CU the self kernel is compiled for (512 / blocks VGPRs per lane)
+SELF_BLOCKS = {"panda": int(os.environ.get("VMV_SELF_BLOCKS", 3)), "ur5": 3}  # workgroups per CU the self kernel is compiled for (512 / blocks VGPRs per lane)
 SELF_DENSE_RATE = 0.5   # groups whose bounding-pair gate fires for at least this share of uniform configurations ...
 SELF_DENSE_MIN_A = 3    # ... and whose A side is at least this large use the pre-test + compaction form
 SPARSE_BATCH = 8        # sparse groups merged per item list (the list holds SPARSE_BATCH * 64 entries = CHUNK * 64)
 SELF_MARGIN = 1e-4      # metres; enclosure of fine spheres by bounding spheres is asserted to 2e-6 by tools/robot_trace.py
-CHUNK = 8  # fine spheres staged in the LDS slab at a time (slab = 1 bounding + CHUNK fine spheres per wave)
+CHUNK = int(os.environ.get('VMV_SELF_CHUNK', 8))  # fine spheres staged in the LDS slab at a time (slab = 1 bounding + CHUNK fine spheres per wave)
 assert SPARSE_BATCH <= 8 and CHUNK <= 8  # vmv::kSelfScratchWords holds 8 * 64 list entries
 
 
@@ -245,7 +245,7 @@ def emit_robot(m):
     L.append("    // Environment half of Robot::fkcc<rake> (reference robots/%s.hh `fkcc`, \"environment vs. robot" % n)
     L.append("    // collisions\"): true = some link group of this rake reports a collision.")
     L.append("    // `skip` (rake-uniform): this rake's answer is not needed; it only keeps the lanes converged.")
-    L.append("    template <int G, bool CLOUDS>")
+    L.append("    template <int G, int V>")
     L.append("    __device__ __forceinline__ bool")
     L.append("    fkcc_env(const vmv::EnvView &E, const float (&q)[kDim], vmv::lds_ptr slab, const bool skip)")
     L.append("    {")
@@ -273,7 +273,7 @@ def emit_robot(m):
         for si, s in enumerate(chunks[0]):
             stage(1 + si, s, "        ")
         em.lines.append("        {")
-        em.lines.append(f"            const bool gate = vmv::env_gate<G, Tab, CLOUDS>(E, slab, scratch, {radii_off[ln]}, {link_class[ln]}, !bad);")
+        em.lines.append(f"            const bool gate = vmv::env_gate<G, Tab, V>(E, slab, scratch, {radii_off[ln]}, {link_class[ln]}, !bad);")
         em.lines.append("            if (VMV_ABLATE_ENV >= 1) bad |= gate;  // measurement aid: no fine phase (wrong answers)")
         em.lines.append("            else if (vmv::wave_any(gate))")
         em.lines.append("            {")
@@ -282,7 +282,7 @@ def emit_robot(m):
             if ci > 0:
                 for si, s in enumerate(ch):
                     stage(1 + si, s, "                ")
-            em.lines.append(f"                vmv::env_fine<G, Tab, CLOUDS>(E, slab, scratch, {len(ch)}, {radii_off[ln] + 1 + done});")
+            em.lines.append(f"                vmv::env_fine<G, Tab, V>(E, slab, scratch, {len(ch)}, {radii_off[ln] + 1 + done});")
             done += len(ch)
         em.lines.append("                bad |= gate && vmv::group_any<G>(vmv::env_flag(scratch));")
         em.lines.append("            }")
@@ -683,11 +683,11 @@ def emit_robot(m):
     L.append(f"        return {n}::static_env_hit(E);")
     L.append("    }")
     L.append(f"    static constexpr int kSelfBlocks = {SELF_BLOCKS.get(n, 2)};  // workgroups per CU the self-collision kernel is compiled for")
-    L.append("    template <int G, bool CLOUDS>")
+    L.append("    template <int G, int V>")
     L.append("    static __device__ __forceinline__ bool")
     L.append("    fkcc_env(const vmv::EnvView &E, const float (&q)[kDim], vmv::lds_ptr slab, const bool skip)")
     L.append("    {")
-    L.append(f"        return {n}::fkcc_env<G, CLOUDS>(E, q, slab, skip);")
+    L.append(f"        return {n}::fkcc_env<G, V>(E, q, slab, skip);")
     L.append("    }")
     L.append("    template <int G>")
     L.append("    static __device__ __forceinline__ bool")

@@ -486,6 +486,9 @@ namespace vmv
         kCuboid = 3,
         kZCuboid = 4
     };
+    // what an environment-kernel variant compiles in: bits 0..4 = primitive lists (PrimType), bit 5 = heightfields and
+    // point clouds
+    constexpr int kEnvFull = 63, kEnvPrims = 31, kEnvZOnly = (1 << kSphere) | (1 << kZCapsule) | (1 << kZCuboid);
     template <int T>
     struct PrimTraits;
     template <> struct PrimTraits<kSphere> { static constexpr int rec = kSphereRec; };
@@ -674,9 +677,11 @@ namespace vmv
     //    largest max_extent in the wave; each lane still applies its own break predicate.
     //    MODE 2 (fine): only the candidates the lane's bounding sphere recorded (see kCandidateMargin).
     //  * `active` only prunes work: inactive lanes do not extend the trip counts and report no hit.
-    //  * CLOUDS = false compiles the heightfield / CAPT / MVT tail out: environments made of primitives only run
-    //    kernels without that code (and its registers; measured 6-8 % on the environment kernel).
-    template <int G, int MODE, bool CLOUDS = true>
+    //  * V selects what is compiled in (kEnvFull / kEnvPrims / kEnvZOnly below): environments made of primitives only
+    //    run kernels without the heightfield / CAPT / MVT tail, and those without general cuboids and capsules also
+    //    without those two lists (their code costs registers even when the lists are empty: 6-8 % and another 5 % on
+    //    the environment kernel).
+    template <int G, int MODE, int V = kEnvFull>
     __device__ __forceinline__ bool
     env_hit(const EnvView &E, float x, float y, float z, float r, bool active, lds_u32 *mask)
     {
@@ -687,29 +692,29 @@ namespace vmv
         bool hit = false;
         if constexpr (MODE == 2)
         {
-            list_masked<kSphere>(E, D.n_sphere, D.off_sphere, D.wbase_sphere, x, y, z, r, rsq, ext, active, hit, mask);
-            list_masked<kCapsule>(E, D.n_capsule, D.off_capsule, D.wbase_capsule, x, y, z, r, rsq, ext, active, hit, mask);
-            list_masked<kZCapsule>(E, D.n_zcapsule, D.off_zcapsule, D.wbase_zcapsule, x, y, z, r, rsq, ext, active, hit, mask);
-            list_masked<kCuboid>(E, D.n_cuboid, D.off_cuboid, D.wbase_cuboid, x, y, z, r, rsq, ext, active, hit, mask);
-            list_masked<kZCuboid>(E, D.n_zcuboid, D.off_zcuboid, D.wbase_zcuboid, x, y, z, r, rsq, ext, active, hit, mask);
+            if constexpr ((V >> kSphere) & 1) list_masked<kSphere>(E, D.n_sphere, D.off_sphere, D.wbase_sphere, x, y, z, r, rsq, ext, active, hit, mask);
+            if constexpr ((V >> kCapsule) & 1) list_masked<kCapsule>(E, D.n_capsule, D.off_capsule, D.wbase_capsule, x, y, z, r, rsq, ext, active, hit, mask);
+            if constexpr ((V >> kZCapsule) & 1) list_masked<kZCapsule>(E, D.n_zcapsule, D.off_zcapsule, D.wbase_zcapsule, x, y, z, r, rsq, ext, active, hit, mask);
+            if constexpr ((V >> kCuboid) & 1) list_masked<kCuboid>(E, D.n_cuboid, D.off_cuboid, D.wbase_cuboid, x, y, z, r, rsq, ext, active, hit, mask);
+            if constexpr ((V >> kZCuboid) & 1) list_masked<kZCuboid>(E, D.n_zcuboid, D.off_zcuboid, D.wbase_zcuboid, x, y, z, r, rsq, ext, active, hit, mask);
         }
         else
         {
             constexpr bool MASK = (MODE == 1);
             const float ext_wave = wave_max_nonneg(active ? ext : 0.0f);
-            list_full<G, kSphere, MASK>(E, D.n_sphere, D.off_sphere, D.off_md_sphere, D.wbase_sphere, x, y, z, r, rsq, ext,
+            if constexpr ((V >> kSphere) & 1) list_full<G, kSphere, MASK>(E, D.n_sphere, D.off_sphere, D.off_md_sphere, D.wbase_sphere, x, y, z, r, rsq, ext,
                                         ext_wave, hit, mask);
-            list_full<G, kCapsule, MASK>(E, D.n_capsule, D.off_capsule, D.off_md_capsule, D.wbase_capsule, x, y, z, r, rsq,
+            if constexpr ((V >> kCapsule) & 1) list_full<G, kCapsule, MASK>(E, D.n_capsule, D.off_capsule, D.off_md_capsule, D.wbase_capsule, x, y, z, r, rsq,
                                          ext, ext_wave, hit, mask);
-            list_full<G, kZCapsule, MASK>(E, D.n_zcapsule, D.off_zcapsule, D.off_md_zcapsule, D.wbase_zcapsule, x, y, z, r,
+            if constexpr ((V >> kZCapsule) & 1) list_full<G, kZCapsule, MASK>(E, D.n_zcapsule, D.off_zcapsule, D.off_md_zcapsule, D.wbase_zcapsule, x, y, z, r,
                                           rsq, ext, ext_wave, hit, mask);
-            list_full<G, kCuboid, MASK>(E, D.n_cuboid, D.off_cuboid, D.off_md_cuboid, D.wbase_cuboid, x, y, z, r, rsq, ext,
+            if constexpr ((V >> kCuboid) & 1) list_full<G, kCuboid, MASK>(E, D.n_cuboid, D.off_cuboid, D.off_md_cuboid, D.wbase_cuboid, x, y, z, r, rsq, ext,
                                         ext_wave, hit, mask);
-            list_full<G, kZCuboid, MASK>(E, D.n_zcuboid, D.off_zcuboid, D.off_md_zcuboid, D.wbase_zcuboid, x, y, z, r, rsq,
+            if constexpr ((V >> kZCuboid) & 1) list_full<G, kZCuboid, MASK>(E, D.n_zcuboid, D.off_zcuboid, D.off_md_zcuboid, D.wbase_zcuboid, x, y, z, r, rsq,
                                          ext, ext_wave, hit, mask);
         }
         hit = hit && active;
-        if constexpr (!CLOUDS) return hit;
+        if constexpr (((V >> 5) & 1) == 0) return hit;
         for (uint32_t hi = 0; hi < D.n_heightfield; ++hi)  // validity.hh:131-137
         {
             if (!wave_any(active && !hit)) break;
@@ -813,7 +818,7 @@ namespace vmv
     }
 
     // Gate pass of one bounding sphere through the broad-phase grid (same answer as env_hit<G, 1>).
-    template <int G, bool CLOUDS = true>
+    template <int G, int V = kEnvFull>
     __device__ __forceinline__ bool
     env_hit_grid(const EnvView &E, const uint32_t cls, float x, float y, float z, float r, bool active, lds_u32 *mask_lane)
     {
@@ -839,13 +844,13 @@ namespace vmv
 #pragma unroll
         for (int w = 0; w < kMaskWords; ++w) cw[w] = (inside && (uint32_t) w < gw) ? cell[w] : 0u;
         if (VMV_ABLATE_ENV == 3) return inside && cw[0] == 0x12345u;  // measurement aid: gate overhead without the walks
-        list_grid<kSphere>(E, D.n_sphere, D.off_sphere, D.wbase_sphere, cw, x, y, z, r, rsq, ext, hit, mask_lane);
-        list_grid<kCapsule>(E, D.n_capsule, D.off_capsule, D.wbase_capsule, cw, x, y, z, r, rsq, ext, hit, mask_lane);
-        list_grid<kZCapsule>(E, D.n_zcapsule, D.off_zcapsule, D.wbase_zcapsule, cw, x, y, z, r, rsq, ext, hit, mask_lane);
-        list_grid<kCuboid>(E, D.n_cuboid, D.off_cuboid, D.wbase_cuboid, cw, x, y, z, r, rsq, ext, hit, mask_lane);
-        list_grid<kZCuboid>(E, D.n_zcuboid, D.off_zcuboid, D.wbase_zcuboid, cw, x, y, z, r, rsq, ext, hit, mask_lane);
+        if constexpr ((V >> kSphere) & 1) list_grid<kSphere>(E, D.n_sphere, D.off_sphere, D.wbase_sphere, cw, x, y, z, r, rsq, ext, hit, mask_lane);
+        if constexpr ((V >> kCapsule) & 1) list_grid<kCapsule>(E, D.n_capsule, D.off_capsule, D.wbase_capsule, cw, x, y, z, r, rsq, ext, hit, mask_lane);
+        if constexpr ((V >> kZCapsule) & 1) list_grid<kZCapsule>(E, D.n_zcapsule, D.off_zcapsule, D.wbase_zcapsule, cw, x, y, z, r, rsq, ext, hit, mask_lane);
+        if constexpr ((V >> kCuboid) & 1) list_grid<kCuboid>(E, D.n_cuboid, D.off_cuboid, D.wbase_cuboid, cw, x, y, z, r, rsq, ext, hit, mask_lane);
+        if constexpr ((V >> kZCuboid) & 1) list_grid<kZCuboid>(E, D.n_zcuboid, D.off_zcuboid, D.wbase_zcuboid, cw, x, y, z, r, rsq, ext, hit, mask_lane);
         hit = hit && active;
-        if constexpr (!CLOUDS) return hit;
+        if constexpr (((V >> 5) & 1) == 0) return hit;
         for (uint32_t hi = 0; hi < D.n_heightfield; ++hi)  // validity.hh:131-137
         {
             if (!wave_any(active && !hit)) break;
@@ -893,7 +898,7 @@ namespace vmv
     //              max_extent.  Hits are OR-ed back per configuration through LDS flags.
     //   env_flag   this lane's "some fine sphere of my configuration hit".
     // `active` (rake-uniform) only prunes work.  Tab::radius(i) reads the robot's __constant__ radius table.
-    template <int G, typename Tab, bool CLOUDS = true>
+    template <int G, typename Tab, int V = kEnvFull>
     __device__ __noinline__ bool
     env_gate(const EnvView E_, lds_cptr slab, lds_ptr scratch_, const int radius_index_, const int grid_class_,
              const bool active)
@@ -905,17 +910,17 @@ namespace vmv
         if (VMV_ABLATE_ENV >= 2) return slab[0] > 1e30f;  // measurement aid: FK only (keeps the FK results alive)
         bool own;
         if (E.dev->masked_fine && E.dev->grid[0].cells != nullptr)
-            own = env_hit_grid<G, CLOUDS>(E, (uint32_t) uniform(grid_class_), slab[0], slab[kRow], slab[2 * kRow],
+            own = env_hit_grid<G, V>(E, (uint32_t) uniform(grid_class_), slab[0], slab[kRow], slab[2 * kRow],
                                   Tab::radius(uniform(radius_index_)), active, mask_lane);
         else if (E.dev->masked_fine)
         {
 #pragma unroll
             for (int w = 0; w < kMaskWords; ++w) mask_lane[w * kWave] = 0u;
-            own = env_hit<G, 1, CLOUDS>(E, slab[0], slab[kRow], slab[2 * kRow], Tab::radius(uniform(radius_index_)), active,
+            own = env_hit<G, 1, V>(E, slab[0], slab[kRow], slab[2 * kRow], Tab::radius(uniform(radius_index_)), active,
                                 mask_lane);
         }
         else
-            own = env_hit<G, 0, CLOUDS>(E, slab[0], slab[kRow], slab[2 * kRow], Tab::radius(uniform(radius_index_)), active,
+            own = env_hit<G, 0, V>(E, slab[0], slab[kRow], slab[2 * kRow], Tab::radius(uniform(radius_index_)), active,
                                 nullptr);
         const bool gate = group_any<G>(own);
         const uint64_t mask = __ballot(gate);
@@ -941,7 +946,7 @@ namespace vmv
         return a;
     }
 
-    template <int G, typename Tab, bool CLOUDS = true>
+    template <int G, typename Tab, int V = kEnvFull>
     __device__ __noinline__ void
     env_fine(const EnvView E_, lds_cptr slab, lds_ptr scratch_, const int n_fine_, const int radii_offset_,
              const int full_ = 0 /* 1: no candidate words (spheres without a bounding-sphere pass: attachments) */)
@@ -969,10 +974,10 @@ namespace vmv
             lds_cptr p = wave_slab + 3 * (s + 1) * kRow + src;
             bool hit;
             if (masked)
-                hit = env_hit<G, 2, CLOUDS>(E, p[0], p[kRow], p[2 * kRow], E.radii[radii_offset + s], act,
+                hit = env_hit<G, 2, V>(E, p[0], p[kRow], p[2 * kRow], E.radii[radii_offset + s], act,
                                     list + 2 * kWave + 4 + src);
             else
-                hit = env_hit<G, 0, CLOUDS>(E, p[0], p[kRow], p[2 * kRow], E.radii[radii_offset + s], act, nullptr);
+                hit = env_hit<G, 0, V>(E, p[0], p[kRow], p[2 * kRow], E.radii[radii_offset + s], act, nullptr);
             if (hit) flags[src] = 1u;
         }
         wave_lds_sync();
