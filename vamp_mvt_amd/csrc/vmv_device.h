@@ -634,17 +634,17 @@ namespace vmv
         for (uint32_t w = 0; w < words; ++w)
         {
             uint32_t m = active ? mask_src[(wbase + w) * kWave] : 0u;
+            // branch-free body: a lane that has run out evaluates record 0 and discards the result (straight-line code
+            // instead of an exec-masked region with its copies of every loop-carried value)
             while (wave_any(m != 0u))
             {
-                if (m != 0u)
-                {
-                    const uint32_t bit = (uint32_t) __ffs((int) m) - 1u;
-                    m &= m - 1u;
-                    lds_cptr rec = E.lds + off + (w * 32u + bit) * REC;  // per-lane record: LDS gather
-                    float v, md, reach;
-                    prim_eval<T>(rec, x, y, z, r, rsq, v, md, reach);
-                    hit |= neg(md - ext) && neg(v);
-                }
+                const bool live = m != 0u;
+                const uint32_t bit = live ? (uint32_t) __ffs((int) m) - 1u : 0u;
+                m &= m - 1u;  // 0 stays 0
+                lds_cptr rec = E.lds + off + (w * 32u + bit) * REC;  // per-lane record: LDS gather
+                float v, md, reach;
+                prim_eval<T>(rec, x, y, z, r, rsq, v, md, reach);
+                hit |= live && neg(md - ext) && neg(v);
             }
         }
     }
@@ -793,25 +793,17 @@ namespace vmv
             const uint32_t k = wbase + w;
             uint32_t m = (k == 0u) ? cw[0] : (k == 1u) ? cw[1] : (k == 2u) ? cw[2] : cw[3];
             uint32_t fine = 0u;
-            while (wave_any(m != 0u))
+            while (wave_any(m != 0u))  // branch-free body, see list_masked
             {
-                if (m != 0u)
-                {
-                    const uint32_t bit = (uint32_t) __ffs((int) m) - 1u;
-                    m &= m - 1u;
-                    if (VMV_ABLATE_ENV == 4)  // measurement aid: the walk without evaluating anything
-                    {
-                        fine |= 1u << bit;
-                        continue;
-                    }
-                    // measurement aid 5: every lane reads record 0 (no gather: broadcast reads)
-                    lds_cptr rec = E.lds + off + ((VMV_ABLATE_ENV == 5) ? 0u : (w * 32u + bit) * REC);
-                    float v, md, reach;
-                    prim_eval<T>(rec, x, y, z, r, rsq, v, md, reach);
-                    hit |= neg(md - ext) && neg(v);
-                    const float tau = reach * (2.0f * kCandidateMargin) + kCandidateMargin * kCandidateMargin;
-                    fine |= (v < tau) ? (1u << bit) : 0u;
-                }
+                const bool live = m != 0u;
+                const uint32_t bit = live ? (uint32_t) __ffs((int) m) - 1u : 0u;
+                m &= m - 1u;
+                lds_cptr rec = E.lds + off + (w * 32u + bit) * REC;
+                float v, md, reach;
+                prim_eval<T>(rec, x, y, z, r, rsq, v, md, reach);
+                hit |= live && neg(md - ext) && neg(v);
+                const float tau = reach * (2.0f * kCandidateMargin) + kCandidateMargin * kCandidateMargin;
+                fine |= (live && v < tau) ? (1u << bit) : 0u;
             }
             mask_lane[(wbase + w) * kWave] = (VMV_ABLATE_ENV == 4 || VMV_ABLATE_ENV == 5) ? 0u : fine;
         }
