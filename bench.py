@@ -66,8 +66,8 @@ def cpu_baseline(env_spec, n_sample, threads, target_seconds=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)  # 200 x 0.33 ms: long enough for the clocks to settle
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--configs", type=int, default=CONFIGS_PER_GPU, help="configurations per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=1 << 21)
