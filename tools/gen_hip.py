@@ -400,7 +400,7 @@ def emit_robot(m):
                     f" && !bad;  // {sg['a']} vs. {ln}")
             sparse = [gi for gi, sg in enumerate(groups) if id(sg) not in dense_ids]
             dense = [gi for gi, sg in enumerate(groups) if id(sg) in dense_ids]
-            em.lines.append(f"{I}if (vmv::wave_any(" + " || ".join(gate_names) + "))")
+            em.lines.append(f"{I}if (VMV_ABLATE_SELF != 2 && vmv::wave_any(" + " || ".join(gate_names) + "))")
             em.lines.append(f"{I}{{")
             em.lines.append(f"{I}    flags[lane] = 0u;")
             J = I + "    "
@@ -450,7 +450,7 @@ def emit_robot(m):
                 # the merged entry list holds at most SPARSE_BATCH * 64 (lane, group) entries
                 for sb in range(0, len(sparse), SPARSE_BATCH):
                     batch_groups = sparse[sb:sb + SPARSE_BATCH]
-                    em.lines.append(f"{J}if (vmv::wave_any(" + " || ".join(gate_names[gi] for gi in batch_groups) + f"))  // sparse groups, chunk {ci}")
+                    em.lines.append(f"{J}if (VMV_ABLATE_SELF != 4 && vmv::wave_any(" + " || ".join(gate_names[gi] for gi in batch_groups) + f"))  // sparse groups, chunk {ci}")
                     em.lines.append(f"{J}{{")
                     K = J + "    "
                     # entries are appended group by group, so entry counts are also item boundaries: the items are
@@ -517,7 +517,7 @@ def emit_robot(m):
                             f"{K}n2 = vmv::deal_append(list2, n2, {gn} && vmv::neg(vmv::sql2_3({em.coord(ba, 0)}, {em.coord(ba, 1)}, "
                             f"{em.coord(ba, 2)}, {em.coord(s, 0)}, {em.coord(s, 1)}, {em.coord(s, 2)}) - {flit(float(f32(rs * rs)))}), {si}u << 6);")
                     em.lines.append(f"{K}vmv::wave_lds_sync();")
-                    em.lines.append(f"{K}for (int base = 0; base < n2; base += vmv::kWave)")
+                    em.lines.append(f"{K}for (int base = 0; base < n2 && VMV_ABLATE_SELF != 1; base += vmv::kWave)")
                     em.lines.append(f"{K}{{")
                     K2 = K + "    "
                     em.lines.append(f"{K2}const int i = base + (int) lane;")

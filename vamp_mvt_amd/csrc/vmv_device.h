@@ -460,6 +460,9 @@ namespace vmv
     //   VMV_PRIMS_SCALAR = 0: from the LDS copy of the block (64-lane broadcast ds_read_b128).
 #ifndef VMV_PRIMS_SCALAR
 #define VMV_PRIMS_SCALAR 1
+#ifndef VMV_ABLATE_SELF
+#define VMV_ABLATE_SELF 0  // measurement aid (tools only): 1 = no dense pair tests, 2 = gates only, 4 = no sparse groups
+#endif
 #ifndef VMV_ABLATE_ENV
 #define VMV_ABLATE_ENV 0  // measurement aid (tools only): 1 = environment kernel without fine phase, 2 = FK only
 #endif
