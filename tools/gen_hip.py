@@ -148,7 +148,7 @@ SELF_DEAL_MAX_A = 40  # A-side spheres kept in registers for the re-dealt self-c
 ENV_CHUNK = {"panda": 5}   # fine spheres per slab chunk in the environment kernels (default CHUNK); a smaller slab
 ENV_BLOCKS = {"panda": 5}  # ... lets five workgroups (20 waves) share a CU's LDS where the registers allow it
 SELF_BLOCKS = {"panda": int(os.environ.get("VMV_SELF_BLOCKS", 3)), "ur5": 3}  # workgroups per CU the self kernel is compiled for (512 / blocks VGPRs per lane)
-SELF_DENSE_RATE = 0.5   # groups whose bounding-pair gate fires for at least this share of uniform configurations ...
+SELF_DENSE_RATE = float(os.environ.get('VMV_SELF_DENSE_RATE', 0.5))   # groups whose bounding-pair gate fires for at least this share of uniform configurations ...
 SELF_DENSE_MIN_A = 3    # ... and whose A side is at least this large use the pre-test + compaction form
 SPARSE_BATCH = 8        # sparse groups merged per item list (the list holds SPARSE_BATCH * 64 entries = CHUNK * 64)
 SELF_MARGIN = 1e-4      # metres; enclosure of fine spheres by bounding spheres is asserted to 2e-6 by tools/robot_trace.py
