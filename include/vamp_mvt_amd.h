@@ -167,6 +167,13 @@ int vmv_env_report_layout(const vmv_env *env, uint32_t *first_word5);
 /* the fine pairs the report covers: n_pairs, and (a, b) sphere indices into pairs2 (may be NULL) */
 int vmv_robot_self_pairs(int robot, size_t *n_pairs, uint16_t *pairs2);
 
+/* sphere_environment_in_collision(environment, x, y, z, r) — collision/validity.hh:47-158, the predicate every fkcc
+ * check is made of (and CAPT::collides / MVT::collides behind it, collision/capt.hh:374-415), for a batch of free
+ * spheres: spheres [n][4] = x y z r, hits[i] = 1 iff sphere i collides with the environment.  Each sphere is its own
+ * replicated rake (lanes independent). */
+int vmv_spheres_in_collision_batch(const vmv_env *env, const float *d_spheres, size_t n, uint8_t *d_hits, void *stream);
+int vmv_spheres_in_collision_batch_host(const vmv_env *env, const float *spheres, size_t n, uint8_t *hits);
+
 /* host-buffer variants (copies included; the PCIe-inclusive path) */
 int vmv_fk_batch_host(int robot, const float *q, size_t n, float *out);
 int vmv_eefk_batch_host(int robot, const float *q, size_t n, float *out);

@@ -1067,12 +1067,26 @@ static inline float sphere_heightfield(const vo_heightfield *a, float x, float y
 /* sphere_environment_in_collision (collision/validity.hh:47-158) on a rake   */
 /* ------------------------------------------------------------------------- */
 
+/* test hook: replaces the exact sqrt of `max_extent` (validity.hh:59) by a caller-supplied one (the reference's
+ * approximate sqrt exported by oracle/_ref).  NULL (default) = correctly rounded sqrtf.  Set before any worker runs. */
+static vo_sqrt_fn vo_sqrt_hook = NULL;
+void vo_set_max_extent_sqrt(vo_sqrt_fn fn) { vo_sqrt_hook = fn; }
+
 static int sphere_environment_in_collision(const vo_env *e, const float *sx, const float *sy, const float *sz,
                                            float sr, int lanes)
 {
     float max_extent[VO_RAKE];
-    /* validity.hh:59 — the reference's approximate sqrt is replaced by the correctly rounded one (header note) */
-    for (int l = 0; l < lanes; ++l) max_extent[l] = sqrtf(dot3(sx[l], sy[l], sz[l], sx[l], sy[l], sz[l])) + sr;
+    /* validity.hh:59 — the reference's approximate sqrt is replaced by the correctly rounded one (header note);
+     * a test may install the reference's own `v * rsqrt_ps(v)` (oracle/_ref) to show the booleans do not depend on it */
+    if (vo_sqrt_hook)
+    {
+        float sq[VO_RAKE] = {0}, rt[VO_RAKE];
+        for (int l = 0; l < lanes; ++l) sq[l] = dot3(sx[l], sy[l], sz[l], sx[l], sy[l], sz[l]);
+        vo_sqrt_hook(sq, rt, VO_RAKE);
+        for (int l = 0; l < lanes; ++l) max_extent[l] = rt[l] + sr;
+    }
+    else
+        for (int l = 0; l < lanes; ++l) max_extent[l] = sqrtf(dot3(sx[l], sy[l], sz[l], sx[l], sy[l], sz[l])) + sr;
 
 #define LIST_LOOP(COUNT, MIN_DISTANCE, TEST)                                  \
     for (size_t i = 0; i < (COUNT); ++i)                                     \

@@ -36,6 +36,11 @@ extern "C" {
 
 typedef struct vo_env vo_env;
 
+/* test hook for the one documented deviation (max_extent's sqrt, collision/validity.hh:59): fn(in, out, n) replaces
+ * sqrtf for the sorted early-break; NULL restores the default. */
+typedef void (*vo_sqrt_fn)(const float *in, float *out, size_t n);
+void vo_set_max_extent_sqrt(vo_sqrt_fn fn);
+
 /* collision/environment.hh:16-88 + bindings/environment.cc:111-163 */
 vo_env *vo_env_create(void);
 void vo_env_destroy(vo_env *e);

@@ -376,6 +376,18 @@ class Environment:
             self._device = dev.value
         return self._handle
 
+    def spheres_in_collision(self, spheres):
+        """sphere_environment_in_collision (collision/validity.hh:47-158) for free spheres [n][4] = x y z r -> bool[n]
+        (each sphere on its own: primitive lists, heightfields, CAPT and MVT clouds)."""
+        s = _f32(spheres)
+        if s.ndim != 2 or s.shape[1] != 4:
+            raise TypeError("spheres must be [n][4] = x y z r")
+        hits = np.zeros(s.shape[0], np.uint8)
+        check(lib.vmv_spheres_in_collision_batch_host(self.handle(), _fp(s), s.shape[0],
+                                                      hits.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8))),
+              "vmv_spheres_in_collision_batch_host")
+        return hits.astype(bool)
+
     # -- inspection (host tables; no GPU needed) ----------------------------------------------------------------
     def host_tables(self):
         """Sorted primitive tables as the kernels see them (built without uploading)."""

@@ -105,6 +105,8 @@ def _load():
         "vmv_eefk_batch_host": (I, [I, c_float_p, S, c_float_p]),
         "vmv_env_attach": (I, [V, c_float_p, c_float_p, S]),
         "vmv_env_detach": (I, [V]),
+        "vmv_spheres_in_collision_batch": (I, [V, V, S, V, V]),
+        "vmv_spheres_in_collision_batch_host": (I, [V, c_float_p, S, ctypes.POINTER(ctypes.c_uint8)]),
         "vmv_validate_batch_host": (I, [I, V, c_float_p, S, c_u64_p]),
         "vmv_validate_motion_batch_host": (I, [I, V, c_float_p, c_float_p, S, c_u64_p]),
         "vmv_halton_configs": (I, [I, ctypes.c_uint64, V, S, V]),

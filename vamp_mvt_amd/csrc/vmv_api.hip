@@ -114,6 +114,28 @@ namespace vmv
         const float u = (float) n / (float) d;
         q[idx] = u * span[j] + lower[j];
     }
+
+    // sphere_environment_in_collision (collision/validity.hh:47-158) for a batch of free spheres, one lane per sphere
+    // (each sphere is its own replicated rake): the primitive lists with their sorted early-break, heightfields,
+    // CAPT and MVT clouds, through the same device functions the robot kernels use (counted loops, no grid).
+    __global__ __launch_bounds__(kBlock) void spheres_env_kernel(const EnvDev *__restrict__ env, const float4 *__restrict__ spheres,
+                                                                  const size_t n, uint8_t *__restrict__ hits)
+    {
+        extern __shared__ __align__(16) float smem[];
+        const uint32_t n_floats = env->n_floats;
+        for (uint32_t i = threadIdx.x; i < n_floats; i += blockDim.x) smem[i] = env->prims[i];
+        __syncthreads();
+        const EnvView E{(env_cptr) env, (lds_cptr) smem, 0u, (lds_cptr) smem};
+        const size_t rounds = (n + (size_t) gridDim.x * kBlock - 1) / ((size_t) gridDim.x * kBlock);
+        for (size_t k = 0; k < rounds; ++k)  // every wave runs every round: env_hit uses wave-wide votes
+        {
+            const size_t i = (k * gridDim.x + blockIdx.x) * (size_t) kBlock + threadIdx.x;
+            const bool active = i < n;
+            const float4 s = active ? spheres[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+            const bool hit = env_hit<1, 0, kEnvFull>(E, s.x, s.y, s.z, s.w, active, nullptr);
+            if (active) hits[i] = hit ? 1 : 0;
+        }
+    }
 }  // namespace vmv
 
 // ---------------------------------------------------------------------------------------------------------
@@ -769,6 +791,21 @@ namespace
         return rc;
     }
 
+    // A finalized environment lives on ONE device (its primitive block, point clouds, grids).  The batched entry
+    // points launch on the caller's current device and stream, so that device must be the environment's.
+    int check_device(const vmv_env *env)
+    {
+        int dev = -1;
+        VMV_HIP(hipGetDevice(&dev));
+        if (dev != env->device)
+        {
+            g_last_error = "environment was finalized on device " + std::to_string(env->device) + ", current device is " +
+                           std::to_string(dev) + " (finalize one environment per device)";
+            return VMV_ERR_INVALID_ARGUMENT;
+        }
+        return VMV_OK;
+    }
+
     int ensure_robot(const vmv_env *cenv, int r)
     {
         vmv_env *env = const_cast<vmv_env *>(cenv);
@@ -795,6 +832,7 @@ extern "C"
         if (!env || !d_q || !d_bits) return VMV_ERR_INVALID_ARGUMENT;
         if (!env->finalized) return VMV_ERR_NOT_FINALIZED;
         if (n == 0) return VMV_OK;
+        if (int rc = check_device(env); rc != VMV_OK) return rc;
         if (int rc = ensure_robot(env, robot); rc != VMV_OK) return rc;
         return kLaunchers[robot]->validate(env->launch[robot], d_q, n, d_bits, static_cast<hipStream_t>(stream), 7);
     }
@@ -805,6 +843,7 @@ extern "C"
         if (!env || !d_q || !d_bits) return VMV_ERR_INVALID_ARGUMENT;
         if (!env->finalized) return VMV_ERR_NOT_FINALIZED;
         if (n == 0) return VMV_OK;
+        if (int rc = check_device(env); rc != VMV_OK) return rc;
         if (int rc = ensure_robot(env, robot); rc != VMV_OK) return rc;
         return kLaunchers[robot]->validate(env->launch[robot], d_q, n, d_bits, static_cast<hipStream_t>(stream), 1);
     }
@@ -824,6 +863,7 @@ extern "C"
         if (!env || !d_a || !d_b || !d_bits) return VMV_ERR_INVALID_ARGUMENT;
         if (!env->finalized) return VMV_ERR_NOT_FINALIZED;
         if (n == 0) return VMV_OK;
+        if (int rc = check_device(env); rc != VMV_OK) return rc;
         if (int rc = ensure_robot(env, robot); rc != VMV_OK) return rc;
         return kLaunchers[robot]->validate_motion(env->launch[robot], d_a, d_b, n, d_bits, static_cast<hipStream_t>(stream));
     }
@@ -867,6 +907,7 @@ extern "C"
         if (n == 0) return VMV_OK;
         int rc = require_device();
         if (rc != VMV_OK) return rc;
+        if ((rc = check_device(env)) != VMV_OK) return rc;
         if ((rc = ensure_robot(env, robot)) != VMV_OK) return rc;
         const size_t ns = (size_t) kRobots[robot].n_spheres, npw = ((size_t) kLaunchers[robot]->n_self_pairs + 31) / 32;
         const size_t qb = n * (size_t) kRobots[robot].dimension * 4, sb = n * ns * 16, eb = n * ns * (vmv::kReportWords + 1) * 4,
@@ -980,24 +1021,63 @@ extern "C"
         return validate_host_common(robot, env, a, b, n, bits);
     }
 
+    // ---- free spheres against the environment ----
+    int vmv_spheres_in_collision_batch(const vmv_env *env, const float *d_spheres, size_t n, uint8_t *d_hits, void *stream)
+    {
+        if (!env || !d_spheres || !d_hits) return VMV_ERR_INVALID_ARGUMENT;
+        if (!env->finalized) return VMV_ERR_NOT_FINALIZED;
+        if (n == 0) return VMV_OK;
+        if (int rc = check_device(env); rc != VMV_OK) return rc;
+        if (int rc = ensure_robot(env, 0); rc != VMV_OK) return rc;  // any robot's image: the counted loops use no grid
+        const size_t blocks = (n + vmv::kBlock - 1) / vmv::kBlock;
+        hipLaunchKernelGGL(vmv::spheres_env_kernel, dim3((unsigned) std::min<size_t>(blocks, 4096)), dim3(vmv::kBlock),
+                           env->base.n_floats * sizeof(float), static_cast<hipStream_t>(stream), env->launch[0].d_env,
+                           reinterpret_cast<const float4 *>(d_spheres), n, d_hits);
+        VMV_HIP(hipGetLastError());
+        return VMV_OK;
+    }
+    int vmv_spheres_in_collision_batch_host(const vmv_env *env, const float *spheres, size_t n, uint8_t *hits)
+    {
+        if (!env || !spheres || !hits) return VMV_ERR_INVALID_ARGUMENT;
+        if (n == 0) return VMV_OK;
+        int rc = require_device();
+        if (rc != VMV_OK) return rc;
+        float *ds = nullptr;
+        uint8_t *dh = nullptr;
+        VMV_HIP(hipMalloc((void **) &ds, n * 16));
+        if (hipMalloc((void **) &dh, n) != hipSuccess)
+        {
+            (void) hipFree(ds);
+            return VMV_ERR_HIP;
+        }
+        if (hipMemcpy(ds, spheres, n * 16, hipMemcpyHostToDevice) != hipSuccess) rc = VMV_ERR_HIP;
+        if (rc == VMV_OK) rc = vmv_spheres_in_collision_batch(env, ds, n, dh, nullptr);
+        if (rc == VMV_OK && hipMemcpy(hits, dh, n, hipMemcpyDeviceToHost) != hipSuccess) rc = VMV_ERR_HIP;
+        (void) hipFree(ds);
+        (void) hipFree(dh);
+        return rc;
+    }
+
     // ---- measurement support ----
     int vmv_time_validate_batch(int robot, const vmv_env *env, const float *d_q, size_t n, uint64_t *d_bits, int iters,
                                 void *stream, float *avg_ms)
     {
         if (!avg_ms || iters < 1) return VMV_ERR_INVALID_ARGUMENT;
         hipStream_t s = static_cast<hipStream_t>(stream);
-        hipEvent_t e0, e1;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
         VMV_HIP(hipEventCreate(&e0));
-        VMV_HIP(hipEventCreate(&e1));
-        VMV_HIP(hipEventRecord(e0, s));
+        hipError_t he = hipEventCreate(&e1);
         int rc = VMV_OK;
-        for (int i = 0; i < iters && rc == VMV_OK; ++i) rc = vmv_validate_batch(robot, env, d_q, n, d_bits, stream);
-        VMV_HIP(hipEventRecord(e1, s));
-        VMV_HIP(hipEventSynchronize(e1));
         float ms = 0.f;
-        VMV_HIP(hipEventElapsedTime(&ms, e0, e1));
-        (void) hipEventDestroy(e0);
-        (void) hipEventDestroy(e1);
+        if (he == hipSuccess) he = hipEventRecord(e0, s);
+        for (int i = 0; he == hipSuccess && i < iters && rc == VMV_OK; ++i)
+            rc = vmv_validate_batch(robot, env, d_q, n, d_bits, stream);
+        if (he == hipSuccess) he = hipEventRecord(e1, s);
+        if (he == hipSuccess) he = hipEventSynchronize(e1);
+        if (he == hipSuccess) he = hipEventElapsedTime(&ms, e0, e1);
+        (void) hipEventDestroy(e0);  // on every exit path
+        if (e1) (void) hipEventDestroy(e1);
+        if (he != hipSuccess) return hip_fail(he, "vmv_time_validate_batch");
         *avg_ms = ms / (float) iters;
         return rc;
     }
