@@ -1405,23 +1405,27 @@ typedef struct
 {
     int robot;
     const vo_env *e;
-    const float *q;
+    const float *q, *goal; /* goal != NULL: edges */
     size_t n;
     uint8_t *out;
 } mt_job;
 static void *mt_run(void *p)
 {
     mt_job *j = (mt_job *) p;
-    vo_validate_batch(j->robot, j->e, j->q, j->n, j->out);
+    if (j->goal)
+        vo_validate_motion_batch(j->robot, j->e, j->q, j->goal, j->n, j->out);
+    else
+        vo_validate_batch(j->robot, j->e, j->q, j->n, j->out);
     return NULL;
 }
-void vo_validate_batch_mt(int robot, const vo_env *e, const float *q, size_t n, uint8_t *out, int threads)
+static void mt_dispatch(int robot, const vo_env *e, const float *q, const float *goal, size_t n, uint8_t *out, int threads)
 {
     if (threads < 1) threads = 1;
     if (threads > 256) threads = 256;
     const size_t dim = vo_robots[robot].dimension;
     pthread_t tid[256];
     mt_job jobs[256];
+    /* small interleaved-free blocks: contiguous shards of ceil(n / threads) units */
     const size_t per = (n + (size_t) threads - 1) / (size_t) threads;
     int started = 0;
     for (int t = 0; t < threads; ++t)
@@ -1429,11 +1433,20 @@ void vo_validate_batch_mt(int robot, const vo_env *e, const float *q, size_t n, 
         const size_t b = per * (size_t) t;
         if (b >= n) break;
         const size_t cnt = (b + per <= n) ? per : n - b;
-        jobs[t] = (mt_job){robot, e, q + b * dim, cnt, out + b};
+        jobs[t] = (mt_job){robot, e, q + b * dim, goal ? goal + b * dim : NULL, cnt, out + b};
         pthread_create(&tid[t], NULL, mt_run, &jobs[t]);
         started++;
     }
     for (int t = 0; t < started; ++t) pthread_join(tid[t], NULL);
+}
+void vo_validate_batch_mt(int robot, const vo_env *e, const float *q, size_t n, uint8_t *out, int threads)
+{
+    mt_dispatch(robot, e, q, NULL, n, out, threads);
+}
+void vo_validate_motion_batch_mt(int robot, const vo_env *e, const float *a, const float *b, size_t n, uint8_t *out,
+                                 int threads)
+{
+    mt_dispatch(robot, e, a, b, n, out, threads);
 }
 
 /* ------------------------------------------------------------------------- */

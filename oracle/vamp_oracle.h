@@ -148,6 +148,8 @@ void vo_validate_batch(int robot, const vo_env *e, const float *q, size_t n, uin
 void vo_validate_motion_batch(int robot, const vo_env *e, const float *a, const float *b, size_t n, uint8_t *out);
 /* same, spread over `threads` pthreads (cpu_baseline leg of bench.py) */
 void vo_validate_batch_mt(int robot, const vo_env *e, const float *q, size_t n, uint8_t *out, int threads);
+void vo_validate_motion_batch_mt(int robot, const vo_env *e, const float *a, const float *b, size_t n, uint8_t *out,
+                                 int threads);
 
 #ifdef __cplusplus
 }

@@ -16,25 +16,41 @@ from vamp_mvt_amd.workloads import (POINT_RADIUS, RADII, WORKSPACE, capsule, env
                                     rot_cuboid, shell_cloud, shell_spec, yaw_cuboid)
 
 
+# The larger robots need room: Fetch's base and Baxter's torso fill the core of the Panda-sized scenes, where no
+# configuration at all is valid (a degenerate test).  Obstacle positions are pushed outwards in x, y for them.
+XY_SCALE = {"panda": 1.0, "ur5": 1.0, "fetch": 1.7, "baxter": 2.2}
+SHELL = {"panda": (0.45, 0.95), "ur5": (0.45, 0.95), "fetch": (0.6, 1.2), "baxter": (0.9, 1.6)}
+
+
+def _spread(p, robot, n_points=1):
+    """scales the x, y of the first n_points points of a parameter vector (a no-op for panda / ur5)"""
+    k = np.float32(XY_SCALE[robot])
+    p = np.array(p, np.float32)
+    for i in range(n_points):
+        p[3 * i] *= k
+        p[3 * i + 1] *= k
+    return p
+
+
 def spec_for(kind, robot="panda", seed=0):
     if kind == "empty":
         return []
     if kind == "cage":
-        return [("sphere", np.array([*c, 0.2], np.float32)) for c in SPHERE_CAGE]
+        return [("sphere", _spread([*c, 0.2], robot)) for c in SPHERE_CAGE]
     if kind == "shell64":
-        return shell_spec(seed)
+        return shell_spec(seed, 32, 32, *SHELL[robot])
     if kind == "mixed":
         rng = np.random.default_rng(seed + 11)
-        spec = shell_spec(seed + 3, 6, 6)
+        spec = shell_spec(seed + 3, 6, 6, *SHELL[robot])
         for _ in range(6):
-            c = rng.uniform([-0.9, -0.9, 0.0], [0.9, 0.9, 1.3]).astype(np.float32)
+            c = _spread(rng.uniform([-0.9, -0.9, 0.0], [0.9, 0.9, 1.3]), robot)
             spec.append(("cuboid", rot_cuboid(c, rng.uniform(-1, 1, 3), rng.uniform(0.03, 0.12, 3))))
         for _ in range(6):
-            p1 = rng.uniform([-0.9, -0.9, 0.0], [0.9, 0.9, 1.3]).astype(np.float32)
+            p1 = _spread(rng.uniform([-0.9, -0.9, 0.0], [0.9, 0.9, 1.3]), robot)
             p2 = (p1 + rng.uniform(-0.3, 0.3, 3)).astype(np.float32)
             spec.append(("capsule", capsule(p1, p2, rng.uniform(0.02, 0.08))))
         for _ in range(6):
-            p1 = rng.uniform([-0.9, -0.9, 0.0], [0.9, 0.9, 1.0]).astype(np.float32)
+            p1 = _spread(rng.uniform([-0.9, -0.9, 0.0], [0.9, 0.9, 1.0]), robot)
             p2 = p1.copy()
             p2[2] += np.float32(rng.uniform(0.1, 0.5))
             spec.append(("capsule", capsule(p1, p2, rng.uniform(0.02, 0.08))))
@@ -43,9 +59,14 @@ def spec_for(kind, robot="panda", seed=0):
         return shell_spec(seed + 21, 150, 100, 0.35, 1.1)
     if kind == "capt":
         r_min, r_max = RADII[robot]
-        spec = shell_spec(seed + 5, 4, 4)
-        spec.append(("capt", (shell_cloud(2000, seed + 7), r_min, r_max, POINT_RADIUS)))
+        spec = shell_spec(seed + 5, 4, 4, *SHELL[robot])
+        k = XY_SCALE[robot] if robot == "baxter" else 1.0
+        spec.append(("capt", (shell_cloud(2000, seed + 7, 0.6 * k, 1.2 * k), r_min, r_max, POINT_RADIUS)))
         return spec
+    if kind == "config3":  # BASELINE config 3: Fetch vs a 10,000-point CAPT cloud (tools/bench_configs.py, same generator)
+        return [("capt", (shell_cloud(10000, 3), *RADII[robot], POINT_RADIUS))]
+    if kind == "config5":  # BASELINE config 5: Baxter, 32 primitives + a 10,000-point CAPT cloud (tools/bench_configs.py)
+        return shell_spec(2, 16, 16, 0.9, 1.6) + [("capt", (shell_cloud(10000, 4, 1.0, 1.8), *RADII[robot], POINT_RADIUS))]
     if kind == "mvt":  # the fork's Multi-level Voxel Table + a few primitives
         r_min, r_max = RADII[robot]
         lo, hi = WORKSPACE[robot]

@@ -107,6 +107,7 @@ class Oracle:
         L.vo_validate_batch.argtypes = [ctypes.c_int, ctypes.c_void_p, _fp, ctypes.c_size_t, _u8p]
         L.vo_validate_motion_batch.argtypes = [ctypes.c_int, ctypes.c_void_p, _fp, _fp, ctypes.c_size_t, _u8p]
         L.vo_validate_batch_mt.argtypes = [ctypes.c_int, ctypes.c_void_p, _fp, ctypes.c_size_t, _u8p, ctypes.c_int]
+        L.vo_validate_motion_batch_mt.argtypes = [ctypes.c_int, ctypes.c_void_p, _fp, _fp, ctypes.c_size_t, _u8p, ctypes.c_int]
 
     def eefk(self, rid, q):
         out = np.zeros((4, 4), np.float32)
@@ -204,11 +205,14 @@ class Oracle:
             self.L.vo_validate_batch(rid, env.h, _f(q), q.shape[0], out.ctypes.data_as(_u8p))
         return out.astype(bool)
 
-    def validate_motion_batch(self, rid, env, a, b):
+    def validate_motion_batch(self, rid, env, a, b, threads=1):
         a = np.ascontiguousarray(a, np.float32)
         b = np.ascontiguousarray(b, np.float32)
         out = np.zeros(a.shape[0], np.uint8)
-        self.L.vo_validate_motion_batch(rid, env.h, _f(a), _f(b), a.shape[0], out.ctypes.data_as(_u8p))
+        if threads > 1:
+            self.L.vo_validate_motion_batch_mt(rid, env.h, _f(a), _f(b), a.shape[0], out.ctypes.data_as(_u8p), threads)
+        else:
+            self.L.vo_validate_motion_batch(rid, env.h, _f(a), _f(b), a.shape[0], out.ctypes.data_as(_u8p))
         return out.astype(bool)
 
 

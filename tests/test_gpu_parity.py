@@ -8,6 +8,7 @@ import pytest
 from envs import make_env
 from oracle_lib import CAGE_GOAL, CAGE_START
 from test_oracle_pins import mt19937_uniform_configs
+from workmix import case_seed, mixed_configs, mixed_edges
 
 pytestmark = pytest.mark.gpu
 ROBOTS = ["panda", "ur5", "fetch", "baxter"]
@@ -27,32 +28,76 @@ def _device(vamp):
     vamp.set_device(0)
 
 
+def _non_degenerate(want, n):
+    """every case must hold a real share of valid AND of invalid answers: an all-zero (or all-one) kernel fails it"""
+    assert 0.05 * n < int(want.sum()) < 0.95 * n, f"degenerate case: {int(want.sum())} of {n} valid"
+
+
 @pytest.mark.parametrize("name", ROBOTS)
 @pytest.mark.parametrize("kind", KINDS)
 def test_validate_batch_bit_exact(vamp, oracle, name, kind):
+    """uniform configurations (whatever their validity) + configurations searched around valid postures (workmix)"""
     env, oenv = make_env(kind, oracle, name)
-    n = 20000 if kind != "capt" else 6000
-    rid, q = uniform_configs(oracle, name, n, seed=hash((name, kind)) % 1000)
+    n = 12000 if kind != "capt" else 4000
+    rid, q = uniform_configs(oracle, name, n, seed=case_seed(name, kind, "uniform") % 100000)
     got = getattr(vamp, name).validate_batch(q, env)
     want = oracle.validate_batch(rid, oenv, q, threads=8)
     assert got.dtype == bool and got.shape == (n,)
     assert np.array_equal(got, want)
+    rid, q, want = mixed_configs(oracle, name, oenv, n, case_seed(name, kind, "mixed"))
+    _non_degenerate(want, n)
+    assert np.array_equal(getattr(vamp, name).validate_batch(q, env), want)
 
 
 @pytest.mark.parametrize("name", ROBOTS)
-@pytest.mark.parametrize("kind", ["empty", "shell64", "mixed", "capt", "heightfield", "attach", "attach_free"])
+@pytest.mark.parametrize("kind", ["empty", "cage", "shell64", "mixed", "capt", "heightfield", "attach", "attach_free"])
 def test_validate_motion_batch_bit_exact(vamp, oracle, name, kind):
-    """Edges with distinct configurations per rake lane: exercises the 8-lane "any lane" gating."""
+    """Edges with distinct configurations per rake lane: exercises the 8-lane "any lane" gating.  Starts near valid
+    postures, steps of several lengths, every 7th edge zero-length (n = 1, block = start)."""
     env, oenv = make_env(kind, oracle, name)
     n = 1500 if kind != "capt" else 600
+    rid, a, b, want = mixed_edges(oracle, name, oenv, n, case_seed(name, kind, "edges"), zero_every=7)
+    _non_degenerate(want, n)
+    assert np.array_equal(getattr(vamp, name).validate_motion_batch(a, b, env), want)
+    # long random edges between uniform configurations (mostly invalid; early-outs at every rake index)
     rid, a = uniform_configs(oracle, name, n, seed=7)
-    rng = np.random.default_rng(8)
-    b = (a + rng.normal(0, 0.35, a.shape)).astype(np.float32)
-    b[::7] = a[::7]  # zero-length edges: n = 1, block = start
-    got = getattr(vamp, name).validate_motion_batch(a, b, env)
-    want = oracle.validate_motion_batch(rid, oenv, a, b)
+    b = (a + np.random.default_rng(8).normal(0, 0.35, a.shape)).astype(np.float32)
+    assert np.array_equal(getattr(vamp, name).validate_motion_batch(a, b, env),
+                          oracle.validate_motion_batch(rid, oenv, a, b, threads=8))
+
+
+@pytest.mark.parametrize("name,kind", [("fetch", "config3"), ("baxter", "config5"), ("panda", "config3"), ("ur5", "config5")])
+def test_baseline_point_cloud_configs_at_cloud_size(vamp, oracle, name, kind):
+    """BASELINE config 3 (Fetch vs a 10,000-point CAPT cloud) and config 5 (Baxter edges vs 32 primitives + a
+    10,000-point CAPT cloud) at the BASELINE cloud size, configurations AND edges, each with a real valid share."""
+    env, oenv = make_env(kind, oracle, name)
+    n = 6000
+    rid, q, want = mixed_configs(oracle, name, oenv, n, case_seed(name, kind, "mixed"))
+    _non_degenerate(want, n)
+    assert np.array_equal(getattr(vamp, name).validate_batch(q, env), want)
+    m = 1200
+    rid, a, b, want_e = mixed_edges(oracle, name, oenv, m, case_seed(name, kind, "edges"), zero_every=11)
+    _non_degenerate(want_e, m)
+    assert np.array_equal(getattr(vamp, name).validate_motion_batch(a, b, env), want_e)
+
+
+@pytest.mark.parametrize("kind", ["shell64", "mixed", "capt", "heightfield", "mvt", "many"])
+def test_free_spheres_against_the_environment(vamp, oracle, kind):
+    """sphere_environment_in_collision (validity.hh:47-158) for free spheres, one predicate at a time: every primitive
+    type, the sorted early-break, heightfields and both point-cloud structures, without a robot in between."""
+    import ctypes
+    env, oenv = make_env(kind, oracle, "panda")
+    rng = np.random.default_rng(case_seed("spheres", kind) % 100000)
+    n = 20000
+    s = np.concatenate([rng.uniform([-1.3, -1.3, -0.3], [1.3, 1.3, 1.6], (n, 3)), rng.uniform(0.005, 0.25, (n, 1))], 1)
+    s = s.astype(np.float32)
+    s[:64, :3] = 0.0  # the origin: max_extent = r exactly (where the reference's v * rsqrt(v) is NaN)
+    got = env.spheres_in_collision(s)
+    f = ctypes.POINTER(ctypes.c_float)
+    want = np.array([bool(oracle.L.vo_sphere_environment_in_collision(oenv.h, s[i, :3].ctypes.data_as(f),
+                                                                      ctypes.c_float(float(s[i, 3])))) for i in range(n)])
     assert np.array_equal(got, want)
-    assert 0 < want.sum() < n or kind == "mixed" or name == "baxter"
+    _non_degenerate(want, n)
 
 
 @pytest.mark.parametrize("name", ROBOTS)
