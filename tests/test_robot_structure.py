@@ -1,0 +1,44 @@
+"""The robot models (vamp_mvt_amd/robots/*.json, from which BOTH the oracle's and the HIP kernels' tables are generated)
+against the collision structure of the reference's generated checkers (tests/golden/groups_<robot>.json, extracted by
+tools/make_groups_golden.py).  CPU only; needs neither a GPU nor /root/reference."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+COUNTS = {"panda": (11, 21, 690), "ur5": (17, 55, 383), "fetch": (15, 48, 2586), "baxter": (33, 349, 1845)}
+
+
+@pytest.mark.parametrize("name", ["panda", "ur5", "fetch", "baxter"])
+def test_model_structure_equals_the_references(golden_dir, name):
+    ref = json.load(open(os.path.join(golden_dir, f"groups_{name}.json")))
+    model = json.load(open(os.path.join(ROOT, "vamp_mvt_amd", "robots", f"{name}.json")))
+    for key in ("dimension", "n_spheres", "resolution", "joint_names"):
+        assert model[key] == ref[key], key
+    for key in ("min_radius", "max_radius"):
+        assert np.float32(model[key]) == np.float32(ref[key]), key
+    assert len(model["outputs"]) == ref["n_total_spheres"]
+    assert [[g["link"], g["bound"], g["fine"]] for g in model["env_groups"]] == ref["env_groups"]
+    assert [[g["a"], g["b"], g["bound_a"], g["bound_b"], g["pairs"]] for g in model["self_groups"]] == ref["self_groups"]
+    assert model["end_effector"] == ref["attach_frame"] and model["attach_links"] == ref["attach_links"]
+    n_env, n_self, n_pairs = COUNTS[name]
+    assert (len(ref["env_groups"]), len(ref["self_groups"]), sum(len(g[4]) for g in ref["self_groups"])) == (n_env, n_self, n_pairs)
+
+
+@pytest.mark.parametrize("name", ["panda", "ur5", "fetch", "baxter"])
+def test_oracle_and_library_tables_equal_the_references(oracle, vamp, golden_dir, name):
+    """what was actually compiled in: the oracle's and the C-ABI library's exported fine-pair tables"""
+    import ctypes
+    ref = json.load(open(os.path.join(golden_dir, f"groups_{name}.json")))
+    pairs = [p for g in ref["self_groups"] for p in g[4]]
+    n = ctypes.c_size_t(0)
+    rid = vamp.lib.vmv_robot_id(name.encode())
+    assert vamp.lib.vmv_robot_self_pairs(rid, ctypes.byref(n), None) == 0 and n.value == len(pairs)
+    got = np.zeros((len(pairs), 2), np.uint16)
+    vamp.lib.vmv_robot_self_pairs(rid, ctypes.byref(n), got.ctypes.data_as(ctypes.POINTER(ctypes.c_uint16)))
+    assert got.tolist() == pairs
+    orid = oracle.robot(name)
+    assert oracle.n_spheres(orid) == ref["n_spheres"] and oracle.n_total_spheres(orid) == ref["n_total_spheres"]
+    assert oracle.dimension(orid) == ref["dimension"] and oracle.resolution(orid) == ref["resolution"]
