@@ -181,6 +181,17 @@ int vmv_validate_batch_host(int robot, const vmv_env *env, const float *q, size_
 int vmv_validate_motion_batch_host(int robot, const vmv_env *env, const float *start, const float *goal, size_t n,
                                    uint64_t *bits);
 
+/* ---- multi-GPU: one process per GPU, every unit independent given the read-only environment ------- */
+/* Contiguous shard [*lo, *hi) of an n-unit batch (configurations or edges) for `rank` of `world`: every boundary except
+ * the last is a multiple of 64, so a shard owns whole validity words and - an edge being a whole sequence of 8-lane
+ * rakes - no rake straddles two GPUs.  Each rank finalizes its own copy of the environment on its device, calls
+ * vmv_validate_batch / vmv_validate_motion_batch on its shard (d_q + lo * dimension, hi - lo units) and the ranks
+ * all-gather the packed words (ncclAllGather of vmv_shard_words(n, world) uint64 per rank; ranks whose shard is
+ * shorter pad with zero words).  That all-gather is the path's only exchange step.  Python: vamp_mvt_amd.sharding. */
+int vmv_shard_range(size_t n, int rank, int world, size_t *lo, size_t *hi);
+/* uint64 words each rank contributes to the all-gather: ceil(ceil(n / 64) / world) */
+size_t vmv_shard_words(size_t n, int world);
+
 /* ---- sampler --------------------------------------------------------------------------------------------- */
 /* <robot>.halton() / RNG.next() — random/halton.hh:75-108 with the default prime bases, generated on the device:
  * fills d_q[n][dimension] with samples skip+1 .. skip+n of the reference's sequence (bit-exact: the sequence's

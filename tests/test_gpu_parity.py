@@ -262,6 +262,29 @@ def test_counted_loop_gate_without_the_grid(vamp, oracle, name, monkeypatch):
     assert np.array_equal(getattr(vamp, name).validate_motion_batch(a, b, env), oracle.validate_motion_batch(rid, oenv, a, b))
 
 
+def test_ill_formed_primitives_take_the_full_loops(vamp, oracle):
+    """canonical parameters are the caller's: cuboid axes that are not unit vectors (or not orthogonal) and a capsule
+    whose rdv is not 1 / |v|^2 make the distance expressions non-1-Lipschitz, which the candidate pruning assumes; such
+    environments must give the reference's full-loop answers all the same"""
+    from envs import build_oracle_env, build_product_env, spec_for
+    spec = spec_for("mixed", "panda", seed=5)
+    out = []
+    for k, (kind, p) in enumerate(spec):
+        p = np.array(p, np.float32)
+        if kind == "cuboid" and k % 2 == 0:
+            p[3:6] *= np.float32(1.7)           # a stretched axis
+            p[6:9] += np.float32(0.4) * p[9:12]  # and a sheared one
+        if kind == "capsule" and k % 3 == 0:
+            p[7] *= np.float32(0.45)
+        out.append((kind, p))
+    env, oenv = build_product_env(out), build_oracle_env(oracle, out)
+    rid, q, want = mixed_configs(oracle, "panda", oenv, 8000, case_seed("ill-formed"))
+    _non_degenerate(want, 8000)
+    assert np.array_equal(vamp.panda.validate_batch(q, env), want)
+    rid, a, b, want_e = mixed_edges(oracle, "panda", oenv, 800, case_seed("ill-formed", "edges"))
+    assert np.array_equal(vamp.panda.validate_motion_batch(a, b, env), want_e)
+
+
 def test_environment_rebuild_after_mutation(vamp, oracle):
     env, oenv = make_env("cage", oracle)
     rid, q = uniform_configs(oracle, "panda", 4000, seed=2)

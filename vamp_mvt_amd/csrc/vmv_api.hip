@@ -573,6 +573,30 @@ extern "C"
             words(D.n_zcuboid, D.wbase_zcuboid);
             D.masked_fine = (w <= (uint32_t) vmv::kMaskWords) ? 1u : 0u;
         }
+        {
+            // The candidate pruning (fine-phase margin, broad-phase grid) assumes 1-Lipschitz primitive distances, which
+            // holds for orthonormal cuboid axes and a capsule whose rdv is 1 / |v|^2.  The ABI accepts arbitrary
+            // canonical parameters (as the reference does), so environments with an ill-formed primitive run the full
+            // sorted loops instead: same answers as the reference's loop, no pruning.
+            bool well_formed = true;
+            const double origin[3] = {0, 0, 0};
+            for (const auto *list : {&env->cuboids, &env->z_cuboids})
+                for (const auto &c : *list)
+                {
+                    double lip = 1.0;
+                    (void) vmv::grid_detail::cuboid_g(c.p, origin, list == &env->z_cuboids, lip);
+                    well_formed = well_formed && std::isfinite(lip) && lip <= 1.0 + 1e-4;
+                }
+            for (const auto *list : {&env->capsules, &env->z_capsules})
+                for (const auto &c : *list)
+                {
+                    const bool z = list == &env->z_capsules;
+                    const double vv = (z ? 0.0 : (double) c.p[3] * c.p[3] + (double) c.p[4] * c.p[4]) + (double) c.p[5] * c.p[5];
+                    const double k = vv * (double) c.p[7];
+                    well_formed = well_formed && std::isfinite(k) && std::fabs(k - 1.0) <= 1e-3;
+                }
+            if (!well_formed) D.masked_fine = 0u;
+        }
         while (block.size() % 4) block.push_back(0.f);
         if (block.size() > kMaxPrimFloats)
         {
@@ -1019,6 +1043,22 @@ extern "C"
     {
         if (!b) return VMV_ERR_INVALID_ARGUMENT;
         return validate_host_common(robot, env, a, b, n, bits);
+    }
+
+    // ---- multi-GPU sharding arithmetic (vamp_mvt_amd/sharding.py: shard_range) ----
+    size_t vmv_shard_words(size_t n, int world)
+    {
+        if (world < 1) return 0;
+        const size_t words = (n + 63) / 64;
+        return (words + (size_t) world - 1) / (size_t) world;
+    }
+    int vmv_shard_range(size_t n, int rank, int world, size_t *lo, size_t *hi)
+    {
+        if (!lo || !hi || world < 1 || rank < 0 || rank >= world) return VMV_ERR_INVALID_ARGUMENT;
+        const size_t per = vmv_shard_words(n, world) * 64;
+        *lo = std::min((size_t) rank * per, n);
+        *hi = std::min(((size_t) rank + 1) * per, n);
+        return VMV_OK;
     }
 
     // ---- free spheres against the environment ----
