@@ -1666,3 +1666,259 @@ size_t vo_filter_centervox(const float *pc, size_t n, float voxel_size, float ma
     free(z_list);
     return failed ? (size_t) -1 : out;
 }
+
+/* ------------------------------------------------------------------------- */
+/* AVX2 build of the same restatement (cpu_baseline of bench.py)             */
+/* ------------------------------------------------------------------------- */
+/* What the reference's SIMD layer (vector/avx.hh: FloatVector<8> = __m256) can do on a batch: one AVX2 lane per
+ * configuration, 8 DISTINCT configurations per rake, per-lane validity masks (the reference's fkcc<8> folds the 8
+ * lanes into one boolean; a batch API needs one boolean per configuration).  Every lane executes exactly the
+ * operations of the scalar port above (one rounding per written operation; -ffp-contract=off; exact vsqrtps), so the
+ * answers are bit-identical to vo_validate_batch - checked by tests/test_oracle_pins.py and again by bench.py before it
+ * times this.  Primitive environments only (no point clouds, heightfields, attachments): the bench workload. */
+#if defined(__x86_64__) && defined(__GNUC__)
+#pragma GCC push_options
+#pragma GCC target("avx2")
+#include <immintrin.h>
+
+typedef __m256 v8f;
+#define V8_SET1(x) _mm256_set1_ps(x)
+
+static inline v8f v8_and(v8f a, v8f b) { return _mm256_and_ps(a, b); }
+static inline unsigned v8_neg_mask(v8f v) { return (unsigned) _mm256_movemask_ps(v); } /* sign bits: `not test_zero` */
+static inline v8f v8_abs(v8f v) { return v8_and(v, _mm256_castsi256_ps(_mm256_set1_epi32(0x7fffffff))); }
+static inline v8f v8_max(v8f a, v8f b) { return _mm256_max_ps(a, b); } /* a > b ? a : b (second operand on NaN) */
+static inline v8f v8_min(v8f a, v8f b) { return _mm256_min_ps(a, b); }
+static inline v8f v8_clamp(v8f v, v8f lo, v8f hi) { return v8_min(v8_max(v, lo), hi); }
+
+/* vector/avx.hh:455-548, the statements of vo_sinf on 8 lanes */
+static inline v8f v8_sin(v8f x)
+{
+    const v8f sign_mask = _mm256_castsi256_ps(_mm256_set1_epi32((int) 0x80000000u));
+    v8f sign_bit = v8_and(x, sign_mask);
+    x = v8_abs(x);
+    v8f y = x * V8_SET1(1.27323954473516f);
+    __m256i j = _mm256_cvtps_epi32(y); /* round to nearest even; out of range -> 0x80000000 */
+    j = _mm256_add_epi32(j, _mm256_set1_epi32(1));
+    j = _mm256_and_si256(j, _mm256_set1_epi32(~1));
+    y = _mm256_cvtepi32_ps(j);
+    const __m256i swap = _mm256_slli_epi32(_mm256_and_si256(j, _mm256_set1_epi32(4)), 29);
+    const __m256i poly = _mm256_cmpeq_epi32(_mm256_and_si256(j, _mm256_set1_epi32(2)), _mm256_setzero_si256());
+    sign_bit = _mm256_xor_ps(sign_bit, _mm256_castsi256_ps(swap));
+    const v8f xmm1 = y * V8_SET1(-0.78515625f);
+    const v8f xmm2 = y * V8_SET1(-2.4187564849853515625e-4f);
+    const v8f xmm3 = y * V8_SET1(-3.77489497744594108e-8f);
+    x = x + xmm1;
+    x = x + xmm2;
+    x = x + xmm3;
+    const v8f z = x * x;
+    v8f yc = V8_SET1(2.443315711809948E-005f);
+    yc = yc * z;
+    yc = yc + V8_SET1(-1.388731625493765E-003f);
+    yc = yc * z;
+    yc = yc + V8_SET1(4.166664568298827E-002f);
+    yc = yc * z;
+    yc = yc * z;
+    const v8f tmp = z * V8_SET1(0.5f);
+    yc = yc - tmp;
+    yc = yc + V8_SET1(1.0f);
+    v8f y2 = V8_SET1(-1.9515295891E-4f);
+    y2 = y2 * z;
+    y2 = y2 + V8_SET1(8.3321608736E-3f);
+    y2 = y2 * z;
+    y2 = y2 + V8_SET1(-1.6666654611E-1f);
+    y2 = y2 * z;
+    y2 = y2 * x;
+    y2 = y2 + x;
+    const v8f pm = _mm256_castsi256_ps(poly);
+    const v8f sel = _mm256_and_ps(pm, y2) + _mm256_andnot_ps(pm, yc); /* and / andnot / add */
+    return _mm256_xor_ps(sel, sign_bit);
+}
+static inline v8f v8_cos(v8f x)
+{
+    const float PI = 3.14159265359f;
+    const v8f v_sq = x + V8_SET1((float) (PI / 2.));
+    const v8f sub = v8_and(_mm256_cmp_ps(v_sq, V8_SET1(PI), _CMP_GE_OQ), V8_SET1((float) (2 * PI)));
+    return v8_sin(v_sq - sub);
+}
+
+#include "gen/robots_fk_v8.inc"
+
+static inline v8f v8_dot3(v8f ax, v8f ay, v8f az, v8f bx, v8f by, v8f bz) { return (ax * bx) + (ay * by) + (az * bz); }
+static inline v8f v8_sql2(v8f ax, v8f ay, v8f az, v8f bx, v8f by, v8f bz)
+{
+    const v8f xs = ax - bx, ys = ay - by, zs = az - bz;
+    return v8_dot3(xs, ys, zs, xs, ys, zs);
+}
+
+/* sphere_environment_in_collision for 8 independent lanes: bit l of the result = lane l's sphere hits something.
+ * `act`: lanes whose answer is wanted.  Lists are sorted by min_distance, so a lane's early break (validity.hh:62-66)
+ * is the per-primitive predicate neg(min_distance - max_extent): once false it stays false. */
+static unsigned v8_env_hit(const vo_env *e, v8f x, v8f y, v8f z, float r, unsigned act)
+{
+    const v8f ext = _mm256_sqrt_ps(v8_dot3(x, y, z, x, y, z)) + V8_SET1(r);
+    const v8f zero = _mm256_setzero_ps(), one = V8_SET1(1.F);
+    unsigned hit = 0;
+#define V8_LIST(COUNT, MD, TEST)                                                       \
+    for (size_t i = 0; i < (COUNT); ++i)                                               \
+    {                                                                                  \
+        const unsigned live = v8_neg_mask(V8_SET1(MD) - ext) & act & ~hit;             \
+        if (!live) break;                                                              \
+        hit |= v8_neg_mask(TEST) & live;                                               \
+    }
+    V8_LIST(e->n_spheres, e->spheres[i].min_distance,
+            ({
+                const vo_sphere *s = &e->spheres[i];
+                const v8f sum = v8_sql2(V8_SET1(s->x), V8_SET1(s->y), V8_SET1(s->z), x, y, z);
+                const v8f rs = V8_SET1(s->r) + V8_SET1(r);
+                sum - rs * rs;
+            }))
+    V8_LIST(e->n_capsules, e->capsules[i].min_distance,
+            ({
+                const vo_capsule *c = &e->capsules[i];
+                const v8f dot = v8_dot3(x - V8_SET1(c->x1), y - V8_SET1(c->y1), z - V8_SET1(c->z1), V8_SET1(c->xv),
+                                        V8_SET1(c->yv), V8_SET1(c->zv));
+                const v8f cdf = v8_clamp(dot * V8_SET1(c->rdv), zero, one);
+                const v8f sum = v8_sql2(x, y, z, V8_SET1(c->x1) + V8_SET1(c->xv) * cdf, V8_SET1(c->y1) + V8_SET1(c->yv) * cdf,
+                                        V8_SET1(c->z1) + V8_SET1(c->zv) * cdf);
+                const v8f rs = V8_SET1(r) + V8_SET1(c->r);
+                sum - rs * rs;
+            }))
+    V8_LIST(e->n_z_capsules, e->z_capsules[i].min_distance,
+            ({
+                const vo_capsule *c = &e->z_capsules[i];
+                const v8f dot = (z - V8_SET1(c->z1)) * V8_SET1(c->zv);
+                const v8f cdf = v8_clamp(dot * V8_SET1(c->rdv), zero, one);
+                const v8f sum = v8_sql2(x, y, z, V8_SET1(c->x1), V8_SET1(c->y1), V8_SET1(c->z1) + V8_SET1(c->zv) * cdf);
+                const v8f rs = V8_SET1(r) + V8_SET1(c->r);
+                sum - rs * rs;
+            }))
+    const v8f rsq = V8_SET1(r * r);
+    V8_LIST(e->n_cuboids, e->cuboids[i].min_distance,
+            ({
+                const float *c = e->cuboids[i].p;
+                const v8f xs = x - V8_SET1(c[0]), ys = y - V8_SET1(c[1]), zs = z - V8_SET1(c[2]);
+                const v8f a1 = v8_max(v8_abs(v8_dot3(V8_SET1(c[3]), V8_SET1(c[4]), V8_SET1(c[5]), xs, ys, zs)) - V8_SET1(c[12]), zero);
+                const v8f a2 = v8_max(v8_abs(v8_dot3(V8_SET1(c[6]), V8_SET1(c[7]), V8_SET1(c[8]), xs, ys, zs)) - V8_SET1(c[13]), zero);
+                const v8f a3 = v8_max(v8_abs(v8_dot3(V8_SET1(c[9]), V8_SET1(c[10]), V8_SET1(c[11]), xs, ys, zs)) - V8_SET1(c[14]), zero);
+                v8_dot3(a1, a2, a3, a1, a2, a3) - rsq;
+            }))
+    V8_LIST(e->n_z_cuboids, e->z_cuboids[i].min_distance,
+            ({
+                const float *c = e->z_cuboids[i].p;
+                const v8f xs = x - V8_SET1(c[0]), ys = y - V8_SET1(c[1]), zs = z - V8_SET1(c[2]);
+                const v8f a1 = v8_max(v8_abs((V8_SET1(c[3]) * xs) + (V8_SET1(c[4]) * ys)) - V8_SET1(c[12]), zero);
+                const v8f a2 = v8_max(v8_abs((V8_SET1(c[6]) * xs) + (V8_SET1(c[7]) * ys)) - V8_SET1(c[13]), zero);
+                const v8f a3 = v8_max(v8_abs(zs) - V8_SET1(c[14]), zero);
+                v8_dot3(a1, a2, a3, a1, a2, a3) - rsq;
+            }))
+#undef V8_LIST
+    return hit;
+}
+
+/* Robot::fkcc on a rake of 8 DISTINCT configurations -> bit l = configuration l is valid */
+static unsigned v8_fkcc(int robot, const vo_env *e, const v8f *q, unsigned lanes)
+{
+    const vo_robot *R = &vo_robots[robot];
+    v8f C[3 * 256];
+    vo_fk_all_v8[robot](q, C);
+    unsigned bad = 0;
+    for (size_t g = 0; g < R->n_env_groups && (lanes & ~bad); ++g)
+    {
+        const vo_env_group *G = &R->env_groups[g];
+        const unsigned gate = v8_env_hit(e, C[3 * G->bound], C[3 * G->bound + 1], C[3 * G->bound + 2], R->radii[G->bound], lanes & ~bad);
+        for (size_t f = 0; f < G->n_fine && (gate & ~bad); ++f)
+        {
+            const unsigned s = R->env_fine[G->fine_offset + f];
+            bad |= v8_env_hit(e, C[3 * s], C[3 * s + 1], C[3 * s + 2], R->radii[s], gate & ~bad);
+        }
+    }
+    for (size_t g = 0; g < R->n_self_groups && (lanes & ~bad); ++g)
+    {
+        const vo_self_group *G = &R->self_groups[g];
+#define V8_PAIR(A, B)                                                                                           \
+    ({                                                                                                          \
+        const v8f rs = V8_SET1(R->radii[A]) + V8_SET1(R->radii[B]);                                             \
+        v8_neg_mask(v8_sql2(C[3 * (A)], C[3 * (A) + 1], C[3 * (A) + 2], C[3 * (B)], C[3 * (B) + 1], C[3 * (B) + 2]) - rs * rs); \
+    })
+        const unsigned gate = V8_PAIR(G->bound_a, G->bound_b) & lanes & ~bad;
+        for (size_t p = 0; p < G->n_pairs && (gate & ~bad); ++p)
+        {
+            const unsigned a = R->self_pairs[G->pair_offset + p][0], b = R->self_pairs[G->pair_offset + p][1];
+            bad |= V8_PAIR(a, b) & gate;
+        }
+#undef V8_PAIR
+    }
+    return lanes & ~bad;
+}
+
+int vo_has_avx2(void) { return __builtin_cpu_supports("avx2") ? 1 : 0; }
+
+/* out[i] = 1 valid / 0 invalid, as vo_validate_batch; returns 0, or -1 for environments this build does not cover */
+int vo_validate_batch_avx2(int robot, const vo_env *e, const float *q, size_t n, uint8_t *out)
+{
+    if (e->n_capts || e->n_mvts || e->n_heightfields || e->attached) return -1;
+    const size_t dim = vo_robots[robot].dimension;
+    for (size_t base = 0; base < n; base += 8)
+    {
+        const unsigned cnt = (n - base < 8) ? (unsigned) (n - base) : 8u;
+        float block[16][8] __attribute__((aligned(32)));
+        for (size_t j = 0; j < dim; ++j)
+            for (unsigned l = 0; l < 8; ++l) block[j][l] = q[(base + (l < cnt ? l : 0)) * dim + j]; /* AoS -> rake */
+        v8f rake[16];
+        for (size_t j = 0; j < dim; ++j) rake[j] = _mm256_load_ps(block[j]);
+        const unsigned valid = v8_fkcc(robot, e, rake, (1u << cnt) - 1u);
+        for (unsigned l = 0; l < cnt; ++l) out[base + l] = (uint8_t) ((valid >> l) & 1u);
+    }
+    return 0;
+}
+#pragma GCC pop_options
+
+typedef struct
+{
+    int robot;
+    const vo_env *e;
+    const float *q;
+    size_t n;
+    uint8_t *out;
+} avx_job;
+static void *avx_run(void *p)
+{
+    avx_job *j = (avx_job *) p;
+    vo_validate_batch_avx2(j->robot, j->e, j->q, j->n, j->out);
+    return NULL;
+}
+int vo_validate_batch_avx2_mt(int robot, const vo_env *e, const float *q, size_t n, uint8_t *out, int threads)
+{
+    if (e->n_capts || e->n_mvts || e->n_heightfields || e->attached) return -1;
+    if (threads < 1) threads = 1;
+    if (threads > 256) threads = 256;
+    const size_t dim = vo_robots[robot].dimension;
+    pthread_t tid[256];
+    avx_job jobs[256];
+    const size_t per = (((n + (size_t) threads - 1) / (size_t) threads) + 7) & ~(size_t) 7; /* whole rakes per shard */
+    int started = 0;
+    for (int t = 0; t < threads; ++t)
+    {
+        const size_t b = per * (size_t) t;
+        if (b >= n) break;
+        jobs[t] = (avx_job){robot, e, q + b * dim, (b + per <= n) ? per : n - b, out + b};
+        pthread_create(&tid[t], NULL, avx_run, &jobs[t]);
+        started++;
+    }
+    for (int t = 0; t < started; ++t) pthread_join(tid[t], NULL);
+    return 0;
+}
+#else
+int vo_has_avx2(void) { return 0; }
+int vo_validate_batch_avx2(int robot, const vo_env *e, const float *q, size_t n, uint8_t *out)
+{
+    (void) robot, (void) e, (void) q, (void) n, (void) out;
+    return -1;
+}
+int vo_validate_batch_avx2_mt(int robot, const vo_env *e, const float *q, size_t n, uint8_t *out, int threads)
+{
+    (void) robot, (void) e, (void) q, (void) n, (void) out, (void) threads;
+    return -1;
+}
+#endif

@@ -42,11 +42,11 @@ class CaptView(ctypes.Structure):
 def build_oracle():
     """Compile oracle/liboracle.so if missing or stale (gcc only; no GPU, no reference needed)."""
     so = os.path.join(ORACLE_DIR, "liboracle.so")
-    if not os.path.exists(os.path.join(ORACLE_DIR, "gen", "robots_gen.inc")):
+    if not all(os.path.exists(os.path.join(ORACLE_DIR, "gen", f)) for f in ("robots_gen.inc", "robots_fk_v8.inc")):
         # generated FK of the oracle (from the committed robot models; needs neither a GPU nor the reference)
         subprocess.check_call([sys.executable, os.path.join(ORACLE_DIR, "..", "tools", "gen_code.py")],
                               stdout=subprocess.DEVNULL)
-    srcs = [os.path.join(ORACLE_DIR, f) for f in ("vamp_oracle.c", "vamp_oracle.h", "gen/robots_gen.inc")]
+    srcs = [os.path.join(ORACLE_DIR, f) for f in ("vamp_oracle.c", "vamp_oracle.h", "gen/robots_gen.inc", "gen/robots_fk_v8.inc")]
     if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["make", "-C", ORACLE_DIR, "liboracle.so"], stdout=subprocess.DEVNULL)
     return so
@@ -107,6 +107,7 @@ class Oracle:
         L.vo_validate_batch.argtypes = [ctypes.c_int, ctypes.c_void_p, _fp, ctypes.c_size_t, _u8p]
         L.vo_validate_motion_batch.argtypes = [ctypes.c_int, ctypes.c_void_p, _fp, _fp, ctypes.c_size_t, _u8p]
         L.vo_validate_batch_mt.argtypes = [ctypes.c_int, ctypes.c_void_p, _fp, ctypes.c_size_t, _u8p, ctypes.c_int]
+        L.vo_validate_batch_avx2_mt.argtypes = [ctypes.c_int, ctypes.c_void_p, _fp, ctypes.c_size_t, _u8p, ctypes.c_int]
         L.vo_validate_motion_batch_mt.argtypes = [ctypes.c_int, ctypes.c_void_p, _fp, _fp, ctypes.c_size_t, _u8p, ctypes.c_int]
 
     def eefk(self, rid, q):
@@ -203,6 +204,17 @@ class Oracle:
             self.L.vo_validate_batch_mt(rid, env.h, _f(q), q.shape[0], out.ctypes.data_as(_u8p), threads)
         else:
             self.L.vo_validate_batch(rid, env.h, _f(q), q.shape[0], out.ctypes.data_as(_u8p))
+        return out.astype(bool)
+
+    def has_avx2(self):
+        return bool(self.L.vo_has_avx2())
+
+    def validate_batch_avx2(self, rid, env, q, threads=1):
+        """the AVX2 rake-of-8 build of validate_batch (primitive environments only)"""
+        q = np.ascontiguousarray(q, np.float32)
+        out = np.zeros(q.shape[0], np.uint8)
+        if self.L.vo_validate_batch_avx2_mt(rid, env.h, _f(q), q.shape[0], out.ctypes.data_as(_u8p), threads) != 0:
+            raise ValueError("environment not covered by the AVX2 build (or no AVX2)")
         return out.astype(bool)
 
     def validate_motion_batch(self, rid, env, a, b, threads=1):

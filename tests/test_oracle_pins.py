@@ -114,3 +114,27 @@ def test_check_bounds(oracle):
     out[3] = lo[3] - np.float32(0.1)
     assert oracle.validate(rid, e, out, check_bounds=True) is False
     assert oracle.validate(rid, e, mid, check_bounds=False) == inside
+
+
+@pytest.mark.parametrize("name", ROBOTS)
+def test_avx2_rake_of_eight_build_equals_the_scalar_port(oracle, name):
+    """bench.py's AVX2 cpu_baseline (8 distinct configurations per rake, per-lane masks) answers bit-identically to the
+    scalar restatement, ragged tail and out-of-range joint values included"""
+    from envs import build_oracle_env, spec_for
+
+    if not oracle.has_avx2():
+        pytest.skip("host CPU without AVX2")
+    rid = oracle.robot(name)
+    lo, span = oracle.bounds(rid)
+    rng = np.random.default_rng(17)
+    for kind in ("shell64", "mixed", "empty"):
+        env = build_oracle_env(oracle, spec_for(kind, name))
+        q = (lo + span * rng.random((20003, len(lo)), dtype=np.float32)).astype(np.float32)
+        q[:16] *= np.float32(3.0)
+        want = oracle.validate_batch(rid, env, q, threads=4)
+        assert 0 < want.sum() < len(q)
+        assert np.array_equal(oracle.validate_batch_avx2(rid, env, q, threads=1), want)
+        assert np.array_equal(oracle.validate_batch_avx2(rid, env, q, threads=3), want)
+    capt = build_oracle_env(oracle, spec_for("capt", name))
+    with pytest.raises(ValueError):
+        oracle.validate_batch_avx2(rid, capt, q[:64])

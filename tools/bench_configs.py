@@ -1,99 +1,129 @@
 #!/usr/bin/env python3
-"""Diagnostic timings of the other BASELINE.json configurations on one MI355X (not the headline metric; that is
-bench.py).  One JSON line per configuration:
+"""The other BASELINE.json configurations (not the headline metric; that is bench.py), on 1..N MI355X.
 
-  config2  Panda, 1M configs vs 64 primitives                  (same as bench.py, for reference)
+    python tools/bench_configs.py [--gpus N] [config2 config3 config4 config5 ...]
+
+  config2  Panda, 1M configs vs 64 primitives                            (same as bench.py, for reference)
   config3  Fetch 8-DoF, 1M configs vs a 10k-point CAPT cloud
-  config4  UR5, 1M edge validations vs 64 primitives           (single GPU share of the 8-GPU job)
-  config5  Baxter 14-DoF, 262,144 edges, 32 primitives + a 10k-point CAPT cloud
-"""
+  config4  UR5 PRM-roadmap shaped: 1M edge validations vs 64 primitives, sharded over the GPUs, RCCL all-gather
+  config5  Baxter 14-DoF FCIT*-shaped batch edge check: 262,144 edges, 32 primitives + a 10k-point CAPT cloud
+
+With N > 1 (one process per GPU; started without a launcher the script starts its own ranks) ONE batch is cut into
+64-aligned contiguous shards (vamp_mvt_amd.sharding.validate_batch_sharded): every rank builds the same batch from the
+same seed, validates its shard against its own copy of the environment and the packed validity words are all-gathered
+(strong scaling).  One JSON line per configuration from rank 0: whole-job units/s with the time taken as the MAX over
+ranks, between barriers."""
 from __future__ import annotations
 
+import argparse
+import importlib.util
 import json
 import os
 import sys
 import time
 
-import numpy as np
-import torch
-
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, ROOT)
-import vamp_mvt_amd as vamp  # noqa: E402
-from vamp_mvt_amd.workloads import POINT_RADIUS, RADII, environment_from_spec, shell_cloud, shell_spec  # noqa: E402
-
-
-def timed(fn, iters=5, warm=2):
-    for _ in range(warm):
-        fn()
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(iters):
-        fn()
-    e1.record()
-    torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / iters
-
-
-def uniform(mod, n, seed):
-    g = torch.Generator(device="cuda").manual_seed(seed)
-    lo = torch.from_numpy(mod.lower_bounds()).cuda()
-    hi = torch.from_numpy(mod.upper_bounds()).cuda()
-    return (lo + (hi - lo) * torch.rand((n, mod.dimension()), generator=g, device="cuda")).contiguous()
-
-
-def edges(mod, n, seed, dmin=0.2, dmax=1.5):
-    a = uniform(mod, n, seed)
-    g = torch.Generator(device="cuda").manual_seed(seed + 1)
-    d = torch.randn((n, mod.dimension()), generator=g, device="cuda")
-    d = d / d.norm(dim=1, keepdim=True)
-    length = dmin + (dmax - dmin) * torch.rand((n, 1), generator=g, device="cuda")
-    return a, (a + d * length).contiguous()
 
 
 def main():
-    which = sys.argv[1:] or ["config2", "config3", "config4", "config5"]
-    vamp.set_device(0)
-    torch.cuda.set_device(0)
-    for cfg in which:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("configs", nargs="*", default=["config2", "config3", "config4", "config5"])
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--scale", type=float, default=1.0, help="fraction of the BASELINE batch sizes (smoke runs)")
+    args = ap.parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # become the launcher BEFORE anything touches the GPU (the package is not imported yet)
+        spec = importlib.util.spec_from_file_location("vmv_sharding", os.path.join(ROOT, "vamp_mvt_amd", "sharding.py"))
+        sharding = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(sharding)
+        sys.exit(sharding.respawn_one_rank_per_gpu(args.gpus, os.path.abspath(__file__), sys.argv[1:]))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import vamp_mvt_amd as vamp
+    from vamp_mvt_amd.sharding import shard_range, validate_batch_sharded
+    from vamp_mvt_amd.workloads import POINT_RADIUS, RADII, environment_from_spec, shell_cloud, shell_spec
+
+    vamp.set_device(local_rank)
+
+    def uniform(mod, n, seed):
+        g = torch.Generator(device=dev).manual_seed(seed)
+        lo = torch.from_numpy(mod.lower_bounds()).to(dev)
+        hi = torch.from_numpy(mod.upper_bounds()).to(dev)
+        return (lo + (hi - lo) * torch.rand((n, mod.dimension()), generator=g, device=dev)).contiguous()
+
+    def edges(mod, n, seed, dmin, dmax):
+        a = uniform(mod, n, seed)
+        g = torch.Generator(device=dev).manual_seed(seed + 1)
+        d = torch.randn((n, mod.dimension()), generator=g, device=dev)
+        d = d / d.norm(dim=1, keepdim=True)
+        length = dmin + (dmax - dmin) * torch.rand((n, 1), generator=g, device=dev)
+        return a, (a + d * length).contiguous()
+
+    for cfg in args.configs:
         if cfg == "config2":
-            mod, n = vamp.panda, 1 << 20
+            mod, n, unit = vamp.panda, int((1 << 20) * args.scale), "checks/s"
             env = environment_from_spec(shell_spec(0))
-            q = uniform(mod, n, 1)
-            bits = torch.zeros((n + 63) // 64, dtype=torch.int64, device="cuda")
-            ms = timed(lambda: mod.validate_bits_device(q, env, bits))
-            unit, frac = "checks/s", float(mod.validate_batch(q[:65536], env).float().mean())
+            a, b = uniform(mod, n, 1), None
         elif cfg == "config3":
-            mod, n = vamp.fetch, 1 << 20
+            mod, n, unit = vamp.fetch, int((1 << 20) * args.scale), "checks/s"
             env = environment_from_spec([("capt", (shell_cloud(10000, 3), *RADII["fetch"], POINT_RADIUS))])
-            q = uniform(mod, n, 2)
-            bits = torch.zeros((n + 63) // 64, dtype=torch.int64, device="cuda")
-            ms = timed(lambda: mod.validate_bits_device(q, env, bits), iters=3, warm=1)
-            unit, frac = "checks/s", float(mod.validate_batch(q[:65536], env).float().mean())
+            a, b = uniform(mod, n, 2), None
         elif cfg == "config4":
-            mod, n = vamp.ur5, 1 << 20
+            mod, n, unit = vamp.ur5, int((1 << 20) * args.scale), "edges/s"
             env = environment_from_spec(shell_spec(0))
-            a, b = edges(mod, n, 3)
-            bits = torch.zeros((n + 63) // 64, dtype=torch.int64, device="cuda")
-            ms = timed(lambda: mod.validate_bits_device(a, env, bits, goals=b), iters=3, warm=1)
-            unit, frac = "edges/s", float(mod.validate_motion_batch(a[:65536], b[:65536], env).float().mean())
+            a, b = edges(mod, n, 3, 0.2, 1.5)
         elif cfg == "config5":
-            mod, n = vamp.baxter, 1 << 18
-            spec = shell_spec(2, 16, 16, 0.9, 1.6) + [("capt", (shell_cloud(10000, 4, 1.0, 1.8), *RADII["baxter"],
-                                                                POINT_RADIUS))]
-            env = environment_from_spec(spec)
+            mod, n, unit = vamp.baxter, int((1 << 18) * args.scale), "edges/s"
+            env = environment_from_spec(shell_spec(2, 16, 16, 0.9, 1.6) +
+                                        [("capt", (shell_cloud(10000, 4, 1.0, 1.8), *RADII["baxter"], POINT_RADIUS))])
             a, b = edges(mod, n, 5, 0.1, 0.6)
-            bits = torch.zeros((n + 63) // 64, dtype=torch.int64, device="cuda")
-            ms = timed(lambda: mod.validate_bits_device(a, env, bits, goals=b), iters=2, warm=1)
-            unit, frac = "edges/s", float(mod.validate_motion_batch(a[:16384], b[:16384], env).float().mean())
         else:
             raise SystemExit(cfg)
-        print(json.dumps({"config": cfg, "robot": mod._name, "n": n, "ms": ms, "value": n / (ms * 1e-3), "unit": unit,
-                          "valid_fraction": frac}), flush=True)
+
+        def job():
+            return validate_batch_sharded(mod, a, env, goals=b, rank=rank, world=world)
+
+        words = job()  # warm: environment upload, robot part, RCCL channels
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.iters):
+            words = job()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        if rank == 0:
+            valid = vamp.unpack_bits(words.cpu().numpy().view(np.uint64), n)
+            lo, hi = shard_range(n, 0, world)
+            print(json.dumps({"config": cfg, "robot": mod._name, "n": n, "n_gpus": world, "ms": dt / args.iters * 1e3,
+                              "value": n * args.iters / dt, "unit": unit, "scaling": "strong",
+                              "valid_fraction": float(valid.mean()), "shard0": [lo, hi],
+                              "exchange": "RCCL all_gather of packed validity words" if world > 1 else "none"}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":
-    t0 = time.time()
     main()
-    print(f"# total {time.time() - t0:.1f}s", flush=True)

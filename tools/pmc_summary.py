@@ -18,7 +18,7 @@ def main():
     out = {}
     waves = {}
     for d in args:
-        for f in glob.glob(f"{d}/*/*counter_collection.csv"):
+        for f in glob.glob(f"{d}/*/*counter_collection.csv") + glob.glob(f"{d}/*counter_collection.csv"):
             agg = collections.defaultdict(list)
             for r in csv.DictReader(open(f)):
                 name = r["Kernel_Name"].split("(")[0].split("::")[-1]
