@@ -122,10 +122,11 @@ namespace vmv
                                                                   const size_t n, uint8_t *__restrict__ hits)
     {
         extern __shared__ __align__(16) float smem[];
-        const uint32_t n_floats = env->n_floats;
+        const uint32_t n_floats = env->n_floats;  // a multiple of 4
         for (uint32_t i = threadIdx.x; i < n_floats; i += blockDim.x) smem[i] = env->prims[i];
         __syncthreads();
-        const EnvView E{(env_cptr) env, (lds_cptr) smem, 0u, (lds_cptr) smem};
+        // [primitive block | CAPT hit-flag rows]; no radius table (free spheres bring their own radius)
+        const EnvView E{(env_cptr) env, (lds_cptr) smem, 0u, (lds_cptr) smem + n_floats + kCaptFlagWords};
         const size_t rounds = (n + (size_t) gridDim.x * kBlock - 1) / ((size_t) gridDim.x * kBlock);
         for (size_t k = 0; k < rounds; ++k)  // every wave runs every round: env_hit uses wave-wide votes
         {
@@ -1071,7 +1072,7 @@ extern "C"
         if (int rc = ensure_robot(env, 0); rc != VMV_OK) return rc;  // any robot's image: the counted loops use no grid
         const size_t blocks = (n + vmv::kBlock - 1) / vmv::kBlock;
         hipLaunchKernelGGL(vmv::spheres_env_kernel, dim3((unsigned) std::min<size_t>(blocks, 4096)), dim3(vmv::kBlock),
-                           env->base.n_floats * sizeof(float), static_cast<hipStream_t>(stream), env->launch[0].d_env,
+                           (env->base.n_floats + vmv::kCaptFlagWords) * sizeof(float), static_cast<hipStream_t>(stream), env->launch[0].d_env,
                            reinterpret_cast<const float4 *>(d_spheres), n, d_hits);
         VMV_HIP(hipGetLastError());
         return VMV_OK;

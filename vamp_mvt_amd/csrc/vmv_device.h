@@ -228,6 +228,10 @@ namespace vmv
     using gu_cptr = const __attribute__((address_space(1))) uint32_t *;
     typedef __attribute__((address_space(1))) v4f g_v4f;
 
+    typedef __attribute__((address_space(3))) uint32_t lds_u32;
+    // per-workgroup LDS words in front of the radius table: one 64-word hit-flag row per wave for the CAPT walk
+    constexpr int kCaptFlagWords = 4 * kWave;
+
     struct EnvView
     {
         env_cptr dev;              // device memory, wave-uniform (scalar loads)
@@ -237,6 +241,12 @@ namespace vmv
                                    // re-dealt items whose sphere index differs per lane (a __constant__ table read
                                    // with a per-lane index is a global load on the critical path of every round)
     };
+
+    // this wave's 64-word hit-flag row of the CAPT walk: kCaptFlagWords words sit right in front of the radius table
+    __device__ __forceinline__ lds_u32 *capt_flag_row(const EnvView &E)
+    {
+        return (lds_u32 *) E.radii - kCaptFlagWords + (threadIdx.x / kWave) * kWave;
+    }
 
     // collision/math.hh:10-42
     __device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, float by, float bz)
@@ -257,11 +267,56 @@ namespace vmv
         return sum - rs * rs;
     }
 
-    // CAPT::collides_simd (collision/capt.hh:428-512), one lane.  The reference's `inbounds.none()` early
-    // returns do not change any lane's answer, so a lane's result is independent of its rake neighbours.
+    __device__ __forceinline__ void wave_lds_sync_()
+    {
+        // same-wave LDS hand-off (DS ops of one wave retire in order; this pins the compiler's order too)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+
+    // ------------------------------------------------------------------------
+    // wave helpers for re-dealing variable-length per-lane work over the 64 lanes.  Every __shfl below runs with all
+    // lanes enabled (ds_bpermute returns 0 from a disabled source lane).
+    // ------------------------------------------------------------------------
+    __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v)
+    {
+        const uint32_t lane = __lane_id();
+#pragma unroll
+        for (int d = 1; d < kWave; d <<= 1)
+        {
+            const uint32_t up = (uint32_t) __shfl_up((int) v, d);
+            v += (lane >= (uint32_t) d) ? up : 0u;
+        }
+        return v;
+    }
+    // first lane o with ends[o] > t, for a non-decreasing `ends` (one value per lane) and t < ends[63]
+    __device__ __forceinline__ uint32_t wave_upper_bound(const uint32_t ends, const uint32_t t)
+    {
+        uint32_t lo = 0u, hi = (uint32_t) kWave - 1u;
+#pragma unroll
+        for (int s = 0; s < 6; ++s)
+        {
+            const uint32_t mid = (lo + hi) >> 1;
+            const bool right = (uint32_t) __shfl((int) ends, (int) mid) <= t;
+            lo = right ? mid + 1u : lo;
+            hi = right ? hi : mid;
+        }
+        return lo < (uint32_t) kWave ? lo : (uint32_t) kWave - 1u;
+    }
+
+    // CAPT::collides_simd (collision/capt.hh:428-512) for the wave's 64 sphere queries (one per lane; the reference's
+    // `inbounds.none()` early returns do not change any lane's answer, so lanes are independent queries).
+    //   1. per lane: top-AABB test (without r_point, as the reference), nlog2 plane descents (top levels in LDS), leaf
+    //      AABB test with r + r_point -> this lane's affordance vectors [start, start + count).
+    //   2. the (query, affordance vector) pairs of ALL lanes are re-dealt over the 64 lanes: 64 vectors of 8 points per
+    //      round, whatever their owner.  A leaf of a 10,000-point cloud holds 18 (Fetch radii) to 87 (Baxter) vectors
+    //      and only the lanes that pass the leaf test have any, so a per-lane walk ran at ~40 % lane utilisation for
+    //      max-over-lanes iterations; re-dealt it is sum / 64 rounds.  Every point is tested with the reference's
+    //      expression (sql2_3 <= (r + r_point)^2); hits are OR-ed per owner through `flags` (this wave's LDS row).
     __device__ __forceinline__ bool
-    capt_collides(env_cptr D, const uint32_t ci, lds_cptr planes_lds, const uint32_t n_lds, float x, float y, float z,
-                  float r, bool active)
+    capt_collides(env_cptr D, const uint32_t ci, lds_cptr planes_lds, const uint32_t n_lds, lds_u32 *flags, float x, float y,
+                  float z, float r, bool active)
     {
         // the top levels of the tree are staged in LDS (planes_lds[0 .. n_lds)); deeper planes come through L1/L2
         const gf_cptr planes = (gf_cptr) D->capt[ci].tests;
@@ -293,33 +348,43 @@ namespace vmv
         if (!wave_any(inb)) return false;
 
         const gu_cptr starts = (gu_cptr) D->capt[ci].aff_starts;
-        uint32_t i = starts[zi];
-        const uint32_t end = inb ? starts[zi + 1] : 0u;
+        const uint32_t start = inb ? starts[zi] : 0u;
+        const uint32_t count = inb ? starts[zi + 1] - start : 0u;
+        const uint32_t ends = wave_inclusive_scan(count);
+        const uint32_t total = (uint32_t) __builtin_amdgcn_readlane((int) ends, kWave - 1);
+        const uint32_t first = ends - count;
+        const uint32_t lane = __lane_id();
+        flags[lane] = 0u;
+        wave_lds_sync_();
         const gf_cptr ax = (gf_cptr) D->capt[ci].aff_x, ay = (gf_cptr) D->capt[ci].aff_y, az = (gf_cptr) D->capt[ci].aff_z;
-        bool hit = false;
-        // per-lane trip counts differ: loop until every lane is past its own end (or has hit)
-        while (wave_any(!hit && i < end))
+        for (uint32_t base = 0; base < total; base += (uint32_t) kWave)
         {
-            if (!hit && i < end)
+            const uint32_t t = base + lane;
+            const bool act = t < total;
+            const uint32_t o = wave_upper_bound(ends, act ? t : 0u);
+            const uint32_t i = (uint32_t) __shfl((int) start, (int) o) + (t - (uint32_t) __shfl((int) first, (int) o));
+            const float qx = __shfl(x, (int) o), qy = __shfl(y, (int) o), qz = __shfl(z, (int) o);
+            const float qr = __shfl(rc_sq, (int) o);
+            if (act)
             {
                 const g_v4f *px = (const g_v4f *) (ax + 8 * (size_t) i);
                 const g_v4f *py = (const g_v4f *) (ay + 8 * (size_t) i);
                 const g_v4f *pz = (const g_v4f *) (az + 8 * (size_t) i);
                 const v4f x0 = px[0], x1 = px[1], y0 = py[0], y1 = py[1], z0 = pz[0], z1 = pz[1];
                 bool h = false;
-                h |= sql2_3(x0.x, y0.x, z0.x, x, y, z) <= rc_sq;
-                h |= sql2_3(x0.y, y0.y, z0.y, x, y, z) <= rc_sq;
-                h |= sql2_3(x0.z, y0.z, z0.z, x, y, z) <= rc_sq;
-                h |= sql2_3(x0.w, y0.w, z0.w, x, y, z) <= rc_sq;
-                h |= sql2_3(x1.x, y1.x, z1.x, x, y, z) <= rc_sq;
-                h |= sql2_3(x1.y, y1.y, z1.y, x, y, z) <= rc_sq;
-                h |= sql2_3(x1.z, y1.z, z1.z, x, y, z) <= rc_sq;
-                h |= sql2_3(x1.w, y1.w, z1.w, x, y, z) <= rc_sq;
-                hit = h;
-                ++i;
+                h |= sql2_3(x0.x, y0.x, z0.x, qx, qy, qz) <= qr;
+                h |= sql2_3(x0.y, y0.y, z0.y, qx, qy, qz) <= qr;
+                h |= sql2_3(x0.z, y0.z, z0.z, qx, qy, qz) <= qr;
+                h |= sql2_3(x0.w, y0.w, z0.w, qx, qy, qz) <= qr;
+                h |= sql2_3(x1.x, y1.x, z1.x, qx, qy, qz) <= qr;
+                h |= sql2_3(x1.y, y1.y, z1.y, qx, qy, qz) <= qr;
+                h |= sql2_3(x1.z, y1.z, z1.z, qx, qy, qz) <= qr;
+                h |= sql2_3(x1.w, y1.w, z1.w, qx, qy, qz) <= qr;
+                if (h) flags[o] = 1u;
             }
         }
-        return hit;
+        wave_lds_sync_();
+        return inb && flags[lane] != 0u;
     }
 
     // MVT::collides (collision/mvt.hh:204-279) == one lane of collides_simd (mvt.hh:282-403; lanes are
@@ -450,8 +515,6 @@ namespace vmv
         }
         return count;
     }
-
-    typedef __attribute__((address_space(3))) uint32_t lds_u32;
 
     // Where the wave-uniform primitive records are read from inside the counted loops.
     //   VMV_PRIMS_SCALAR = 1: straight from the environment block through the scalar cache (s_load_dwordx4 into
@@ -727,7 +790,7 @@ namespace vmv
         {
             const bool act = active && !hit;
             if (!wave_any(act)) break;
-            hit |= capt_collides(Dp, ci, E.lds + D.n_floats, (ci == 0) ? E.capt0_planes_in_lds : 0u, x, y, z, r, act);
+            hit |= capt_collides(Dp, ci, E.lds + D.n_floats, (ci == 0) ? E.capt0_planes_in_lds : 0u, capt_flag_row(E), x, y, z, r, act);
         }
         for (uint32_t mi = 0; mi < D.n_mvt; ++mi)  // validity.hh:149-155
         {
@@ -855,7 +918,7 @@ namespace vmv
         {
             const bool act = active && !hit;
             if (!wave_any(act)) break;
-            hit |= capt_collides(Dp, ci, E.lds + D.n_floats, (ci == 0) ? E.capt0_planes_in_lds : 0u, x, y, z, r, act);
+            hit |= capt_collides(Dp, ci, E.lds + D.n_floats, (ci == 0) ? E.capt0_planes_in_lds : 0u, capt_flag_row(E), x, y, z, r, act);
         }
         for (uint32_t mi = 0; mi < D.n_mvt; ++mi)
         {
@@ -867,13 +930,7 @@ namespace vmv
 #undef D
     }
 
-    __device__ __forceinline__ void wave_lds_sync()
-    {
-        // same-wave LDS hand-off (DS ops of one wave retire in order; this pins the compiler's order too)
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    }
+    __device__ __forceinline__ void wave_lds_sync() { wave_lds_sync_(); }
 
     // per-wave LDS scratch behind the slab: lane list [64], hit flags [64], k [4], candidate words [kMaskWords][64]
     constexpr int kScratchWords = 2 * kWave + 4 + kMaskWords * kWave;
