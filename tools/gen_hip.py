@@ -674,7 +674,11 @@ def emit_robot(m):
     L.append(f"    static constexpr int kResolution = {n}::kResolution;")
     L.append(f"    static constexpr int kSlabSpheres = {n}::kSlabSpheres;")
     L.append(f"    static constexpr int kSelfSlabSpheres = {n}::kSelfSlabSpheres;")
+    L.append("#ifdef VMV_ENV_BLOCKS  // tuning knob (tools/build_variant.py)")
+    L.append("    static constexpr int kEnvBlocks = VMV_ENV_BLOCKS;")
+    L.append("#else")
     L.append(f"    static constexpr int kEnvBlocks = {ENV_BLOCKS.get(n, 4)};  // workgroups per CU the environment kernel is compiled for")
+    L.append("#endif")
     L.append(f"    static constexpr int kNRadii = {n}::kNRadii;")
     L.append(f"    static constexpr int kNStaticLinks = {n}::kNStaticLinks;")
     L.append(f"    static constexpr int kNSelfPairs = {n}::kNSelfPairs;")
