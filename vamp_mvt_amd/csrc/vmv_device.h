@@ -352,36 +352,50 @@ namespace vmv
         const uint32_t count = inb ? starts[zi + 1] - start : 0u;
         const uint32_t ends = wave_inclusive_scan(count);
         const uint32_t total = (uint32_t) __builtin_amdgcn_readlane((int) ends, kWave - 1);
-        const uint32_t first = ends - count;
+        const uint32_t vbase = start - (ends - count);  // vector index of item t of this lane's query = vbase + t
         const uint32_t lane = __lane_id();
         flags[lane] = 0u;
         wave_lds_sync_();
         const gf_cptr ax = (gf_cptr) D->capt[ci].aff_x, ay = (gf_cptr) D->capt[ci].aff_y, az = (gf_cptr) D->capt[ci].aff_z;
+        // software-pipelined rounds: the owner search of round k + 1 (six dependent ds_bpermute) is issued while the
+        // twelve 16-byte loads of round k are in flight; the walk is bound by these latencies, not by arithmetic
+        struct Who
+        {
+            uint32_t o, i;
+            float qx, qy, qz, qr;
+            bool act;
+        };
+        auto who = [&](const uint32_t base) -> Who
+        {
+            Who w;
+            const uint32_t t = base + lane;
+            w.act = t < total;
+            w.o = wave_upper_bound(ends, w.act ? t : 0u);
+            w.i = (uint32_t) __shfl((int) vbase, (int) w.o) + t;
+            w.qx = __shfl(x, (int) w.o), w.qy = __shfl(y, (int) w.o), w.qz = __shfl(z, (int) w.o);
+            w.qr = __shfl(rc_sq, (int) w.o);
+            return w;
+        };
+        Who cur = who(0u);
         for (uint32_t base = 0; base < total; base += (uint32_t) kWave)
         {
-            const uint32_t t = base + lane;
-            const bool act = t < total;
-            const uint32_t o = wave_upper_bound(ends, act ? t : 0u);
-            const uint32_t i = (uint32_t) __shfl((int) start, (int) o) + (t - (uint32_t) __shfl((int) first, (int) o));
-            const float qx = __shfl(x, (int) o), qy = __shfl(y, (int) o), qz = __shfl(z, (int) o);
-            const float qr = __shfl(rc_sq, (int) o);
-            if (act)
-            {
-                const g_v4f *px = (const g_v4f *) (ax + 8 * (size_t) i);
-                const g_v4f *py = (const g_v4f *) (ay + 8 * (size_t) i);
-                const g_v4f *pz = (const g_v4f *) (az + 8 * (size_t) i);
-                const v4f x0 = px[0], x1 = px[1], y0 = py[0], y1 = py[1], z0 = pz[0], z1 = pz[1];
-                bool h = false;
-                h |= sql2_3(x0.x, y0.x, z0.x, qx, qy, qz) <= qr;
-                h |= sql2_3(x0.y, y0.y, z0.y, qx, qy, qz) <= qr;
-                h |= sql2_3(x0.z, y0.z, z0.z, qx, qy, qz) <= qr;
-                h |= sql2_3(x0.w, y0.w, z0.w, qx, qy, qz) <= qr;
-                h |= sql2_3(x1.x, y1.x, z1.x, qx, qy, qz) <= qr;
-                h |= sql2_3(x1.y, y1.y, z1.y, qx, qy, qz) <= qr;
-                h |= sql2_3(x1.z, y1.z, z1.z, qx, qy, qz) <= qr;
-                h |= sql2_3(x1.w, y1.w, z1.w, qx, qy, qz) <= qr;
-                if (h) flags[o] = 1u;
-            }
+            const size_t off = cur.act ? 8 * (size_t) cur.i : 0;  // lanes past the end read vector 0 and discard it
+            const g_v4f *px = (const g_v4f *) (ax + off);
+            const g_v4f *py = (const g_v4f *) (ay + off);
+            const g_v4f *pz = (const g_v4f *) (az + off);
+            const v4f x0 = px[0], x1 = px[1], y0 = py[0], y1 = py[1], z0 = pz[0], z1 = pz[1];
+            const Who nxt = who(base + (uint32_t) kWave);  // (past the last round: all lanes inactive, harmless)
+            bool h = false;
+            h |= sql2_3(x0.x, y0.x, z0.x, cur.qx, cur.qy, cur.qz) <= cur.qr;
+            h |= sql2_3(x0.y, y0.y, z0.y, cur.qx, cur.qy, cur.qz) <= cur.qr;
+            h |= sql2_3(x0.z, y0.z, z0.z, cur.qx, cur.qy, cur.qz) <= cur.qr;
+            h |= sql2_3(x0.w, y0.w, z0.w, cur.qx, cur.qy, cur.qz) <= cur.qr;
+            h |= sql2_3(x1.x, y1.x, z1.x, cur.qx, cur.qy, cur.qz) <= cur.qr;
+            h |= sql2_3(x1.y, y1.y, z1.y, cur.qx, cur.qy, cur.qz) <= cur.qr;
+            h |= sql2_3(x1.z, y1.z, z1.z, cur.qx, cur.qy, cur.qz) <= cur.qr;
+            h |= sql2_3(x1.w, y1.w, z1.w, cur.qx, cur.qy, cur.qz) <= cur.qr;
+            if (h && cur.act) flags[cur.o] = 1u;
+            cur = nxt;
         }
         wave_lds_sync_();
         return inb && flags[lane] != 0u;
