@@ -30,7 +30,7 @@ def test_no_torch_types_in_the_abi():
 
 def test_robot_constants_match_oracle_and_models(vamp, oracle):
     here = os.path.dirname(os.path.abspath(__file__))
-    assert vamp.robots() == ROBOTS
+    assert vamp.robots() == ROBOTS and list(vamp.robots) == ROBOTS
     for name in ROBOTS:
         mod = getattr(vamp, name)
         rid = oracle.robot(name)

@@ -21,7 +21,7 @@ import numpy as np
 from . import _lib
 from ._lib import VmvError, check, lib
 
-__all__ = ["Sphere", "Cuboid", "Cylinder", "Attachment", "filter_pointcloud", "HeightField", "make_heightfield", "png_to_heightfield", "Environment", "robots", "device_count", "set_device", "abi_version",
+__all__ = ["robots", "Sphere", "Cuboid", "Cylinder", "Attachment", "filter_pointcloud", "HeightField", "make_heightfield", "png_to_heightfield", "Environment", "device_count", "set_device", "abi_version",
            "VmvError", "unpack_bits", "POINT_RADIUS"]
 
 POINT_RADIUS = 0.0025  # reference src/vamp/constants.py:25
@@ -41,9 +41,15 @@ def set_device(index: int) -> None:
     check(lib.vmv_set_device(int(index)), "vmv_set_device")
 
 
-def robots():
-    """reference bindings/python.cc.in `robots()`"""
-    return [lib.vmv_robot_name(i).decode() for i in range(lib.vmv_num_robots())]
+class _RobotList(list):
+    """`vamp.robots` is a list in the reference package (src/vamp/__init__.py:46) and `robots()` a function in its
+    extension module (bindings/python.cc.in); this is both"""
+
+    def __call__(self):
+        return list(self)
+
+
+robots = _RobotList(lib.vmv_robot_name(i).decode() for i in range(lib.vmv_num_robots()))
 
 
 def _f32(a, shape=None):
@@ -629,8 +635,53 @@ class _Robot(types.ModuleType):
 
 _EMPTY_ENVIRONMENT = Environment()
 
-for _name in robots():
+from . import api as _api  # noqa: E402  (the reference's planner-facing names; needs the classes above)
+from .api import (AORRTCSettings, FCITNeighborParams, FCITSettings, PRMNeighborParams, PRMSettings,  # noqa: E402,F401
+                  RRTCSettings, SimplifyRoutine, SimplifySettings, results_to_dict, DEFAULT_ITERATIONS, ROBOT_RRT_RANGES)
+
+_ROBOT_MODULES = {}
+for _name in robots:
     _mod = _Robot(_name)
+    _api.install(_mod)
+    _ROBOT_MODULES[_name] = _mod
     globals()[_name] = _mod
     sys.modules[_mod.__name__] = _mod
     __all__.append(_name)
+__all__ += ["configure_robot_and_planner_with_kwargs", "problem_dict_to_vamp", "results_to_dict", "RRTCSettings",
+            "PRMSettings", "PRMNeighborParams", "FCITSettings", "FCITNeighborParams", "AORRTCSettings", "SimplifySettings",
+            "SimplifyRoutine"]
+
+
+def configure_robot_and_planner_with_kwargs(robot_name: str, planner_name: str, **kwargs):
+    """vamp.configure_robot_and_planner_with_kwargs (reference src/vamp/__init__.py:69-139)"""
+    if robot_name not in _ROBOT_MODULES:
+        raise AttributeError(robot_name)
+    return _api.configure_robot_and_planner_with_kwargs(_ROBOT_MODULES, robot_name, planner_name, **kwargs)
+
+
+def problem_dict_to_vamp(problem, ignore_names=()):
+    """vamp.problem_dict_to_vamp (reference src/vamp/__init__.py:140-186): MotionBenchMaker scene dict -> Environment.
+    Cylinders become capsules, except in the "box" problem where they are over-approximated by cuboids."""
+    env = Environment()
+    for obj in problem["sphere"]:
+        if obj["name"] not in ignore_names:
+            s = Sphere(obj["position"], obj["radius"])
+            s.name = obj["name"]
+            env.add_sphere(s)
+    for obj in problem["cylinder"]:
+        if obj["name"] in ignore_names:
+            continue
+        if problem["problem"] == "box":
+            c = Cuboid(obj["position"], obj["orientation_euler_xyz"], [obj["radius"], obj["radius"], obj["length"] / 2])
+            c.name = obj["name"]
+            env.add_cuboid(c)
+        else:
+            c = Cylinder(obj["position"], obj["orientation_euler_xyz"], obj["radius"], obj["length"])
+            c.name = obj["name"]
+            env.add_capsule(c)
+    for obj in problem["box"]:
+        if obj["name"] not in ignore_names:
+            c = Cuboid(obj["position"], obj["orientation_euler_xyz"], obj["half_extents"])
+            c.name = obj["name"]
+            env.add_cuboid(c)
+    return env

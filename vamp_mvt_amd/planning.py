@@ -129,19 +129,23 @@ def rrtc(robot, start, goal, environment, settings: RRTCSettings | None = None, 
     """Minimal RRT-Connect on the batched validity API (same structure as planning/rrtc.hh:33-245)."""
     s = settings or RRTCSettings()
     rng = sampler or Halton(robot)
-    start, goal = np.asarray(start, np.float32), np.asarray(goal, np.float32)
+    start = np.asarray(start, np.float32)
+    goals = np.asarray(goal, np.float32)
+    goals = goals[None] if goals.ndim == 1 else goals  # the reference's multi-goal form: every goal roots the goal tree
     res = PlanningResult()
 
     def motion(a, b):
         res.validity_calls += 1
         return robot.validate_motion_batch(np.ascontiguousarray(a), np.ascontiguousarray(b), environment)
 
-    if bool(motion(start[None], goal[None])[0]):  # rrtc.hh:60-73
-        res.path, res.size = [start, goal], [1, 1]
+    direct = motion(np.repeat(start[None], len(goals), 0), goals)  # rrtc.hh:60-73
+    if direct.any():
+        res.path, res.size = [start, goals[int(np.argmax(direct))]], [1, 1]
         return res
     tree_a, tree_b = _Tree(len(start)), _Tree(len(start))
     tree_a.add(start, 0)
-    tree_b.add(goal, 0)
+    for g in goals:
+        tree_b.add(g, len(tree_b.parent))
     a_is_start = True
     while res.iterations < s.max_iterations and len(tree_a.parent) + len(tree_b.parent) < s.max_samples:
         res.iterations += 1
