@@ -348,15 +348,37 @@ namespace vmv
         if (!wave_any(inb)) return false;
 
         const gu_cptr starts = (gu_cptr) D->capt[ci].aff_starts;
-        const uint32_t start = inb ? starts[zi] : 0u;
-        const uint32_t count = inb ? starts[zi + 1] - start : 0u;
+        uint32_t start = inb ? starts[zi] : 0u;
+        uint32_t count = inb ? starts[zi + 1] - start : 0u;
+        const gf_cptr ax = (gf_cptr) D->capt[ci].aff_x, ay = (gf_cptr) D->capt[ci].aff_y, az = (gf_cptr) D->capt[ci].aff_z;
+        // every query tests its own FIRST vector (the leaf's representative point and the first afforded points) before
+        // anything is re-dealt: no owner search, and a sphere well inside the cloud usually hits right there - the
+        // reference's early exit for the common case
+        bool first_hit = false;
+        if (count != 0u)
+        {
+            const g_v4f *px = (const g_v4f *) (ax + 8 * (size_t) start);
+            const g_v4f *py = (const g_v4f *) (ay + 8 * (size_t) start);
+            const g_v4f *pz = (const g_v4f *) (az + 8 * (size_t) start);
+            const v4f x0 = px[0], x1 = px[1], y0 = py[0], y1 = py[1], z0 = pz[0], z1 = pz[1];
+            first_hit |= sql2_3(x0.x, y0.x, z0.x, x, y, z) <= rc_sq;
+            first_hit |= sql2_3(x0.y, y0.y, z0.y, x, y, z) <= rc_sq;
+            first_hit |= sql2_3(x0.z, y0.z, z0.z, x, y, z) <= rc_sq;
+            first_hit |= sql2_3(x0.w, y0.w, z0.w, x, y, z) <= rc_sq;
+            first_hit |= sql2_3(x1.x, y1.x, z1.x, x, y, z) <= rc_sq;
+            first_hit |= sql2_3(x1.y, y1.y, z1.y, x, y, z) <= rc_sq;
+            first_hit |= sql2_3(x1.z, y1.z, z1.z, x, y, z) <= rc_sq;
+            first_hit |= sql2_3(x1.w, y1.w, z1.w, x, y, z) <= rc_sq;
+        }
+        start += 1u;
+        count = (first_hit || count == 0u) ? 0u : count - 1u;
+        if (!wave_any(count != 0u)) return first_hit;
         const uint32_t ends = wave_inclusive_scan(count);
         const uint32_t total = (uint32_t) __builtin_amdgcn_readlane((int) ends, kWave - 1);
         const uint32_t vbase = start - (ends - count);  // vector index of item t of this lane's query = vbase + t
         const uint32_t lane = __lane_id();
         flags[lane] = 0u;
         wave_lds_sync_();
-        const gf_cptr ax = (gf_cptr) D->capt[ci].aff_x, ay = (gf_cptr) D->capt[ci].aff_y, az = (gf_cptr) D->capt[ci].aff_z;
         // software-pipelined rounds: the owner search of round k + 1 (six dependent ds_bpermute) is issued while the
         // twelve 16-byte loads of round k are in flight; the walk is bound by these latencies, not by arithmetic
         struct Who
@@ -398,7 +420,7 @@ namespace vmv
             cur = nxt;
         }
         wave_lds_sync_();
-        return inb && flags[lane] != 0u;
+        return first_hit || (inb && flags[lane] != 0u);
     }
 
     // MVT::collides (collision/mvt.hh:204-279) == one lane of collides_simd (mvt.hh:282-403; lanes are
