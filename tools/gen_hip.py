@@ -146,14 +146,23 @@ def gate_rates(m, n=4096, seed=0):
 
 SELF_DEAL_MAX_A = 40  # A-side spheres kept in registers for the re-dealt self-collision form
 ENV_CHUNK = {"panda": 5}   # fine spheres per slab chunk in the environment kernels (default CHUNK); a smaller slab
-ENV_BLOCKS = {"panda": 5}  # ... lets five workgroups (20 waves) share a CU's LDS where the registers allow it
-SELF_BLOCKS = {"panda": int(os.environ.get("VMV_SELF_BLOCKS", 3)), "ur5": 3}  # workgroups per CU the self kernel is compiled for (512 / blocks VGPRs per lane)
+ENV_BLOCKS = {"panda": 5, "baxter": 5}  # (baxter: 0.331 -> 0.307 ms per 1M configs at 5)  # ... lets five workgroups (20 waves) share a CU's LDS where the registers allow it
+# workgroups per CU the self kernel is compiled for (512 / blocks VGPRs per lane) and fine spheres per slab chunk of the
+# self-collision kernels.  Panda, measured (blocks x chunk, self kernel ms per 1M configs): 3x8 0.145, 4x8 0.133,
+# 4x7 0.127, 4x6 0.126, 4x5 0.132, 4x4 0.140, 5x5 0.210 - with chunks of 8 the fourth workgroup did not fit the LDS.
+SELF_BLOCKS = {"panda": 4, "ur5": 3, "baxter": 3}  # (baxter: 0.289 -> 0.227 ms at 3; fetch is faster at 2 than at 3)
+SELF_CHUNK = {"panda": 6}
+for _r in ("panda", "ur5", "fetch", "baxter"):  # tuning knobs: VMV_SELF_BLOCKS_<ROBOT>, VMV_SELF_CHUNK_<ROBOT>
+    if f"VMV_SELF_BLOCKS_{_r.upper()}" in os.environ:
+        SELF_BLOCKS[_r] = int(os.environ[f"VMV_SELF_BLOCKS_{_r.upper()}"])
+    if f"VMV_SELF_CHUNK_{_r.upper()}" in os.environ:
+        SELF_CHUNK[_r] = int(os.environ[f"VMV_SELF_CHUNK_{_r.upper()}"])
 SELF_DENSE_RATE = float(os.environ.get('VMV_SELF_DENSE_RATE', 0.5))   # groups whose bounding-pair gate fires for at least this share of uniform configurations ...
 SELF_DENSE_MIN_A = 3    # ... and whose A side is at least this large use the pre-test + compaction form
 SPARSE_BATCH = 8        # sparse groups merged per item list (the list holds SPARSE_BATCH * 64 entries = CHUNK * 64)
 SELF_MARGIN = 1e-4      # metres; enclosure of fine spheres by bounding spheres is asserted to 2e-6 by tools/robot_trace.py
-CHUNK = int(os.environ.get('VMV_SELF_CHUNK', 8))  # fine spheres staged in the LDS slab at a time (slab = 1 bounding + CHUNK fine spheres per wave)
-assert SPARSE_BATCH <= 8 and CHUNK <= 8  # vmv::kSelfScratchWords holds 8 * 64 list entries
+DEFAULT_CHUNK = 8  # fine spheres staged in the LDS slab at a time (slab = 1 bounding + CHUNK fine spheres per wave)
+assert SPARSE_BATCH <= 8 and DEFAULT_CHUNK <= 8  # vmv::kSelfScratchWords holds 8 * 64 list entries
 
 
 GRID_CLASSES = 4  # vmv::kGridClasses
@@ -205,6 +214,8 @@ def static_links(m):
 
 def emit_robot(m):
     n = m["name"]
+    CHUNK = SELF_CHUNK.get(n, DEFAULT_CHUNK)
+    assert 1 <= CHUNK <= 8
     L = []
     dim = m["dimension"]
     links = m["links"]
@@ -222,7 +233,7 @@ def emit_robot(m):
         radii_off[ln] = len(radii_tab)
         radii_tab += [radii[g["bound"]]] + [radii[s] for s in g["fine"]]
     max_group = max(len(g["fine"]) for g in m["env_groups"])
-    env_chunk = ENV_CHUNK.get(n, CHUNK)
+    env_chunk = ENV_CHUNK.get(n, DEFAULT_CHUNK)
     slab_spheres = 1 + min(env_chunk, max_group)
     self_slab_spheres = 1 + min(CHUNK, max_group)
 
