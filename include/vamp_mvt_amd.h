@@ -174,6 +174,13 @@ int vmv_robot_self_pairs(int robot, size_t *n_pairs, uint16_t *pairs2);
 int vmv_spheres_in_collision_batch(const vmv_env *env, const float *d_spheres, size_t n, uint8_t *d_hits, void *stream);
 int vmv_spheres_in_collision_batch_host(const vmv_env *env, const float *spheres, size_t n, uint8_t *hits);
 
+/* <robot>.filter_self_from_pointcloud(pc, point_radius, configuration, environment) — bindings/robot_helper.hh:284-322:
+ * keeps the points whose sphere (x, y, z, point_radius) neither overlaps a collision sphere of the robot at `q`
+ * (sphere_sphere_sql2 < 0) nor collides with the environment; order preserved.  Host buffers; out may be NULL (count only);
+ * VMV_ERR_CAPACITY if out is too small. */
+int vmv_filter_self_from_pointcloud(int robot, const vmv_env *env, const float *q, const float *points_xyz, size_t n,
+                                    float point_radius, float *out_xyz, size_t capacity, size_t *n_out);
+
 /* host-buffer variants (copies included; the PCIe-inclusive path) */
 int vmv_fk_batch_host(int robot, const float *q, size_t n, float *out);
 int vmv_eefk_batch_host(int robot, const float *q, size_t n, float *out);

@@ -1667,6 +1667,31 @@ size_t vo_filter_centervox(const float *pc, size_t n, float voxel_size, float ma
     return failed ? (size_t) -1 : out;
 }
 
+/* bindings/robot_helper.hh:284-322: keep the points whose sphere neither overlaps a robot sphere at q nor the environment */
+size_t vo_filter_self_from_pointcloud(int robot, const vo_env *e, const float *q, const float *pts, size_t n, float r,
+                                      float *out)
+{
+    const vo_robot *R = &vo_robots[robot];
+    float c[3 * 256];
+    R->fk_fine(q, c);
+    size_t m = 0;
+    for (size_t i = 0; i < n; ++i)
+    {
+        const float x = pts[3 * i], y = pts[3 * i + 1], z = pts[3 * i + 2];
+        int valid = 1;
+        for (size_t s = 0; s < R->n_spheres && valid; ++s)
+            if (signbit_set(sphere_sphere_sql2(c[3 * s], c[3 * s + 1], c[3 * s + 2], R->radii[s], x, y, z, r)) ||
+                sphere_environment_in_collision(e, &x, &y, &z, r, 1))
+                valid = 0;
+        if (valid)
+        {
+            out[3 * m] = x, out[3 * m + 1] = y, out[3 * m + 2] = z;
+            ++m;
+        }
+    }
+    return m;
+}
+
 /* ------------------------------------------------------------------------- */
 /* AVX2 build of the same restatement (cpu_baseline of bench.py)             */
 /* ------------------------------------------------------------------------- */

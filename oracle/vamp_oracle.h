@@ -150,6 +150,9 @@ void vo_validate_motion_batch(int robot, const vo_env *e, const float *a, const 
 void vo_validate_batch_mt(int robot, const vo_env *e, const float *q, size_t n, uint8_t *out, int threads);
 void vo_validate_motion_batch_mt(int robot, const vo_env *e, const float *a, const float *b, size_t n, uint8_t *out,
                                  int threads);
+/* <robot>.filter_self_from_pointcloud (bindings/robot_helper.hh:284-322): out[m][3], returns m */
+size_t vo_filter_self_from_pointcloud(int robot, const vo_env *e, const float *q, const float *points_xyz, size_t n,
+                                      float point_radius, float *out_xyz);
 /* AVX2 build of vo_validate_batch: one vector lane per configuration, 8 distinct configurations per rake (the shape of
  * the reference's vector/avx.hh), bit-identical answers.  Primitive environments only; -1 otherwise or without AVX2. */
 int vo_has_avx2(void);

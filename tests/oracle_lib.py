@@ -107,6 +107,8 @@ class Oracle:
         L.vo_validate_batch.argtypes = [ctypes.c_int, ctypes.c_void_p, _fp, ctypes.c_size_t, _u8p]
         L.vo_validate_motion_batch.argtypes = [ctypes.c_int, ctypes.c_void_p, _fp, _fp, ctypes.c_size_t, _u8p]
         L.vo_validate_batch_mt.argtypes = [ctypes.c_int, ctypes.c_void_p, _fp, ctypes.c_size_t, _u8p, ctypes.c_int]
+        L.vo_filter_self_from_pointcloud.argtypes = [ctypes.c_int, ctypes.c_void_p, _fp, _fp, ctypes.c_size_t, ctypes.c_float, _fp]
+        L.vo_filter_self_from_pointcloud.restype = ctypes.c_size_t
         L.vo_validate_batch_avx2_mt.argtypes = [ctypes.c_int, ctypes.c_void_p, _fp, ctypes.c_size_t, _u8p, ctypes.c_int]
         L.vo_validate_motion_batch_mt.argtypes = [ctypes.c_int, ctypes.c_void_p, _fp, _fp, ctypes.c_size_t, _u8p, ctypes.c_int]
 
@@ -205,6 +207,13 @@ class Oracle:
         else:
             self.L.vo_validate_batch(rid, env.h, _f(q), q.shape[0], out.ctypes.data_as(_u8p))
         return out.astype(bool)
+
+    def filter_self_from_pointcloud(self, rid, env, q, pts, r):
+        q = np.ascontiguousarray(q, np.float32)
+        pts = np.ascontiguousarray(pts, np.float32).reshape(-1, 3)
+        out = np.zeros((max(len(pts), 1), 3), np.float32)
+        m = self.L.vo_filter_self_from_pointcloud(rid, env.h, _f(q), _f(pts), len(pts), float(r), _f(out))
+        return out[:m].copy()
 
     def has_avx2(self):
         return bool(self.L.vo_has_avx2())

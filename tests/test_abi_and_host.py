@@ -160,3 +160,21 @@ def test_product_never_touches_the_oracle():
             if f.endswith((".py", ".h", ".hip", ".inc", ".cpp")):
                 text = open(os.path.join(root, f), errors="replace").read()
                 assert "liboracle" not in text and "vamp_oracle" not in text and "oracle_lib" not in text, f
+
+
+def test_shape_attributes_mirror_the_reference_names(vamp, oracle):
+    """read-only parameters of bindings/environment.cc:22-98; min_distance equals the oracle's (collision/shapes.hh)"""
+    c = vamp.Cuboid([0.4, -0.2, 0.7], [0.3, -0.5, 1.1], [0.1, 0.05, 0.2])
+    assert (c.x, c.y, c.z) == tuple(float(v) for v in c.params[:3]) and c.axis_3_r == float(c.params[14])
+    assert abs(c.axis_1_x ** 2 + c.axis_1_y ** 2 + c.axis_1_z ** 2 - 1.0) < 1e-6
+    e = oracle.env()
+    e.add_cuboid(c.params)
+    assert np.float32(c.min_distance) == e.cuboids(False)[0, 15]
+    k = vamp.Cylinder([0.4, 0.3, 0.5], [0.2, 0.9, -0.4], 0.06, 0.5)
+    assert abs(k.x2 - (k.x1 + k.xv)) < 1e-6 and k.r == float(np.float32(0.06)) and abs(k.rdv * (k.xv ** 2 + k.yv ** 2 + k.zv ** 2) - 1) < 1e-5
+    e = oracle.env()
+    e.add_capsule(k.params)
+    assert np.float32(k.min_distance) == e.capsules(False)[0, 8]
+    s = vamp.Sphere([0.3, 0.4, 0.0], 0.1)
+    s.name = "ball"
+    assert s.name == "ball" and abs(s.min_distance - 0.4) < 1e-6 and s.position == [s.x, s.y, s.z]

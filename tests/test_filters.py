@@ -203,3 +203,28 @@ def test_gpu_capt_build_drives_validation(vamp, oracle):
     lo, span = oracle.bounds(rid)
     q = (lo + span * np.random.default_rng(3).random((6000, len(lo)), dtype=np.float32)).astype(np.float32)
     assert np.array_equal(vamp.fetch.validate_batch(q, e), oracle.validate_batch(rid, oe, q, threads=8))
+
+
+# ---- <robot>.filter_self_from_pointcloud (bindings/robot_helper.hh:284-322) ------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["panda", "fetch"])
+def test_gpu_filter_self_from_pointcloud_matches_oracle(vamp, oracle, name):
+    """points overlapping the robot at a configuration or the environment are dropped, the rest keep their order"""
+    from envs import make_env
+    vamp.set_device(0)
+    env, oenv = make_env("mixed", oracle, name)
+    rid = oracle.robot(name)
+    lo, span = oracle.bounds(rid)
+    rng = np.random.default_rng(5)
+    q = (lo + span * np.float32(0.5)).astype(np.float32)
+    fk = oracle.fk(rid, q)
+    near = fk[rng.integers(len(fk), size=4000), :3] + rng.normal(0, 0.05, (4000, 3))  # around the robot's spheres
+    far = rng.uniform([-1.2, -1.2, -0.2], [1.2, 1.2, 1.6], (6000, 3))
+    pc = np.concatenate([near, far]).astype(np.float32)
+    rng.shuffle(pc)
+    for r in (0.0025, 0.03):
+        want = oracle.filter_self_from_pointcloud(rid, oenv, q, pc, r)
+        got = getattr(vamp, name).filter_self_from_pointcloud(pc, r, q, env)
+        assert 0.05 * len(pc) < len(want) < 0.95 * len(pc)
+        assert got.shape == want.shape and np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    assert getattr(vamp, name).filter_self_from_pointcloud(pc[:0], 0.01, q, env).shape == (0, 3)

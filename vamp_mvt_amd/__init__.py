@@ -129,6 +129,19 @@ class Cuboid:
     x = property(lambda s: float(s.params[0]))
     y = property(lambda s: float(s.params[1]))
     z = property(lambda s: float(s.params[2]))
+    # read-only parameters under the reference's names (bindings/environment.cc:60-98)
+    axis_1_x, axis_1_y, axis_1_z = (property(lambda s, i=i: float(s.params[i])) for i in (3, 4, 5))
+    axis_2_x, axis_2_y, axis_2_z = (property(lambda s, i=i: float(s.params[i])) for i in (6, 7, 8))
+    axis_3_x, axis_3_y, axis_3_z = (property(lambda s, i=i: float(s.params[i])) for i in (9, 10, 11))
+    axis_1_r, axis_2_r, axis_3_r = (property(lambda s, i=i: float(s.params[i])) for i in (12, 13, 14))
+
+    @property
+    def min_distance(self):
+        """collision/shapes.hh:52-67 (computed by the C ABI's host code, the same function the kernels' tables use)"""
+        e = Environment()
+        e.add_cuboid(self)
+        t = e.host_tables()
+        return float((t["cuboids"] if len(t["cuboids"]) else t["z_cuboids"])[0, 15])
 
 
 class Attachment:
@@ -231,6 +244,20 @@ class Cylinder:
         rdv = f(1.0 / float(dot))  # static_cast<float>(1.0 / dot): double division, then narrowed
         self.params = np.array([p1[0], p1[1], p1[2], v[0], v[1], v[2], radius, rdv], np.float32)
         self.name = ""
+
+    # read-only parameters under the reference's names (bindings/environment.cc:42-58)
+    x1, y1, z1, xv, yv, zv, r, rdv = (property(lambda s, i=i: float(s.params[i])) for i in range(8))
+    x2 = property(lambda s: float(np.float32(s.params[0]) + np.float32(s.params[3])))
+    y2 = property(lambda s: float(np.float32(s.params[1]) + np.float32(s.params[4])))
+    z2 = property(lambda s: float(np.float32(s.params[2]) + np.float32(s.params[5])))
+
+    @property
+    def min_distance(self):
+        """collision/shapes.hh:165-189"""
+        e = Environment()
+        e.add_capsule(self)
+        t = e.host_tables()
+        return float((t["capsules"] if len(t["capsules"]) else t["z_capsules"])[0, 8])
 
     @classmethod
     def from_canonical(cls, params8):
@@ -547,6 +574,18 @@ class _Robot(types.ModuleType):
         """<robot>.fk(q) -> list[Sphere] — robot_helper.hh:234-247."""
         out = self.fk_batch(_f32(configuration, (self._dim,))[None, :])[0]
         return [Sphere(s[:3], s[3]) for s in out]
+
+    def filter_self_from_pointcloud(self, pc, point_radius, configuration, environment: Environment | None = None):
+        """<robot>.filter_self_from_pointcloud — robot_helper.hh:284-322: the points [m][3] of `pc` whose sphere of radius
+        `point_radius` touches neither the robot at `configuration` nor the environment (order preserved)."""
+        pts = _f32(pc).reshape(-1, 3)
+        q = _f32(configuration, (self._dim,))
+        out = np.zeros((max(len(pts), 1), 3), np.float32)
+        m = ctypes.c_size_t(0)
+        check(lib.vmv_filter_self_from_pointcloud(self._id, self._env(environment), _fp(q), _fp(pts), len(pts),
+                                                  float(point_radius), _fp(out), len(pts), ctypes.byref(m)),
+              "vmv_filter_self_from_pointcloud")
+        return out[:m.value].copy()
 
     # batched calls --------------------------------------------------------------------------------------------
     def _env(self, environment):

@@ -105,6 +105,7 @@ def _load():
         "vmv_eefk_batch_host": (I, [I, c_float_p, S, c_float_p]),
         "vmv_env_attach": (I, [V, c_float_p, c_float_p, S]),
         "vmv_env_detach": (I, [V]),
+        "vmv_filter_self_from_pointcloud": (I, [I, V, c_float_p, c_float_p, S, F, c_float_p, S, c_size_p]),
         "vmv_shard_range": (I, [S, I, I, c_size_p, c_size_p]),
         "vmv_shard_words": (S, [S, I]),
         "vmv_spheres_in_collision_batch": (I, [V, V, S, V, V]),

@@ -118,8 +118,11 @@ namespace vmv
     // sphere_environment_in_collision (collision/validity.hh:47-158) for a batch of free spheres, one lane per sphere
     // (each sphere is its own replicated rake): the primitive lists with their sorted early-break, heightfields,
     // CAPT and MVT clouds, through the same device functions the robot kernels use (counted loops, no grid).
+    // robot_spheres (optional, [n_robot] x y z r of one configuration, <robot>.filter_self_from_pointcloud): a sphere
+    // also "hits" when it overlaps one of them (sphere_sphere_sql2 < 0, strict, robot_helper.hh:306-307)
     __global__ __launch_bounds__(kBlock) void spheres_env_kernel(const EnvDev *__restrict__ env, const float4 *__restrict__ spheres,
-                                                                  const size_t n, uint8_t *__restrict__ hits)
+                                                                  const size_t n, uint8_t *__restrict__ hits,
+                                                                  const float4 *__restrict__ robot_spheres, const int n_robot)
     {
         extern __shared__ __align__(16) float smem[];
         const uint32_t n_floats = env->n_floats;  // a multiple of 4
@@ -133,7 +136,12 @@ namespace vmv
             const size_t i = (k * gridDim.x + blockIdx.x) * (size_t) kBlock + threadIdx.x;
             const bool active = i < n;
             const float4 s = active ? spheres[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-            const bool hit = env_hit<1, 0, kEnvFull>(E, s.x, s.y, s.z, s.w, active, nullptr);
+            bool hit = env_hit<1, 0, kEnvFull>(E, s.x, s.y, s.z, s.w, active, nullptr);
+            for (int k = 0; k < n_robot; ++k)  // wave-uniform records (scalar loads)
+            {
+                const float4 a = robot_spheres[k];
+                hit |= neg(sphere_sphere_sql2(a.x, a.y, a.z, a.w, s.x, s.y, s.z, s.w));
+            }
             if (active) hits[i] = hit ? 1 : 0;
         }
     }
@@ -1073,9 +1081,68 @@ extern "C"
         const size_t blocks = (n + vmv::kBlock - 1) / vmv::kBlock;
         hipLaunchKernelGGL(vmv::spheres_env_kernel, dim3((unsigned) std::min<size_t>(blocks, 4096)), dim3(vmv::kBlock),
                            (env->base.n_floats + vmv::kCaptFlagWords) * sizeof(float), static_cast<hipStream_t>(stream), env->launch[0].d_env,
-                           reinterpret_cast<const float4 *>(d_spheres), n, d_hits);
+                           reinterpret_cast<const float4 *>(d_spheres), n, d_hits, (const float4 *) nullptr, 0);
         VMV_HIP(hipGetLastError());
         return VMV_OK;
+    }
+    int vmv_filter_self_from_pointcloud(int robot, const vmv_env *env, const float *q, const float *points_xyz, size_t n,
+                                        float point_radius, float *out_xyz, size_t capacity, size_t *n_out)
+    {
+        if (!robot_ok(robot)) return VMV_ERR_UNKNOWN_ROBOT;
+        if (!env || !q || (n && !points_xyz) || !n_out) return VMV_ERR_INVALID_ARGUMENT;
+        if (!env->finalized) return VMV_ERR_NOT_FINALIZED;
+        *n_out = 0;
+        if (n == 0) return VMV_OK;
+        int rc = require_device();
+        if (rc != VMV_OK) return rc;
+        if ((rc = check_device(env)) != VMV_OK) return rc;
+        if ((rc = ensure_robot(env, 0)) != VMV_OK) return rc;
+        const size_t dim = (size_t) kRobots[robot].dimension, ns = (size_t) kRobots[robot].n_spheres;
+        std::vector<float> spheres(4 * n);
+        for (size_t i = 0; i < n; ++i)
+        {
+            std::memcpy(&spheres[4 * i], points_xyz + 3 * i, 12);
+            spheres[4 * i + 3] = point_radius;
+        }
+        float *dq = nullptr, *drs = nullptr, *ds = nullptr;
+        uint8_t *dh = nullptr;
+        std::vector<uint8_t> hits(n);
+        auto release = [&]()
+        {
+            (void) hipFree(dq);
+            (void) hipFree(drs);
+            (void) hipFree(ds);
+            (void) hipFree(dh);
+        };
+        if (hipMalloc((void **) &dq, dim * 4) != hipSuccess || hipMalloc((void **) &drs, ns * 16) != hipSuccess ||
+            hipMalloc((void **) &ds, n * 16) != hipSuccess || hipMalloc((void **) &dh, n) != hipSuccess ||
+            hipMemcpy(dq, q, dim * 4, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(ds, spheres.data(), n * 16, hipMemcpyHostToDevice) != hipSuccess)
+        {
+            release();
+            return VMV_ERR_HIP;
+        }
+        rc = kLaunchers[robot]->fk(dq, 1, drs, nullptr);  // Robot::sphere_fk of the one configuration
+        if (rc == VMV_OK)
+        {
+            const size_t blocks = (n + vmv::kBlock - 1) / vmv::kBlock;
+            hipLaunchKernelGGL(vmv::spheres_env_kernel, dim3((unsigned) std::min<size_t>(blocks, 4096)), dim3(vmv::kBlock),
+                               (env->base.n_floats + vmv::kCaptFlagWords) * sizeof(float), nullptr, env->launch[0].d_env,
+                               reinterpret_cast<const float4 *>(ds), n, dh, reinterpret_cast<const float4 *>(drs), (int) ns);
+            if (hipGetLastError() != hipSuccess || hipMemcpy(hits.data(), dh, n, hipMemcpyDeviceToHost) != hipSuccess)
+                rc = VMV_ERR_HIP;
+        }
+        release();
+        if (rc != VMV_OK) return rc;
+        size_t m = 0;
+        for (size_t i = 0; i < n; ++i)
+            if (!hits[i])
+            {
+                if (out_xyz && m < capacity) std::memcpy(out_xyz + 3 * m, points_xyz + 3 * i, 12);
+                ++m;
+            }
+        *n_out = m;
+        return (out_xyz && m > capacity) ? VMV_ERR_CAPACITY : VMV_OK;
     }
     int vmv_spheres_in_collision_batch_host(const vmv_env *env, const float *spheres, size_t n, uint8_t *hits)
     {
