@@ -323,3 +323,31 @@ def test_full_size_properties(vamp, oracle):
     assert np.array_equal(v[idx], oracle.validate_batch(rid, oenv, q[idx], threads=8))
     # host-buffer path == device-buffer path
     assert np.array_equal(p.validate_batch(q[:200000], env), v[:200000])
+
+
+def test_fused_one_fk_kernel_is_bit_exact_too(oracle):
+    """VMV_FUSED_KERNEL=1 (opt-in; measured slower): both halves of fkcc along one walk of the chain, one
+    FK per configuration.  Read once per process, so the fused path runs in a child process."""
+    import subprocess
+    import sys
+    code = r"""
+import sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import numpy as np
+import vamp_mvt_amd as vamp
+from oracle_lib import Oracle
+from envs import make_env
+from workmix import case_seed, mixed_configs
+vamp.set_device(0)
+o = Oracle()
+for name in ("panda", "ur5"):
+    for kind in ("shell64", "mixed", "cage", "empty"):
+        env, oenv = make_env(kind, o, name)
+        rid, q, want = mixed_configs(o, name, oenv, 8000, case_seed(name, kind, "fused"))
+        assert np.array_equal(getattr(vamp, name).validate_batch(q, env), want), (name, kind)
+        assert np.array_equal(getattr(vamp, name).validate_batch(q[:77], env), want[:77]), (name, kind)
+print("fused ok")
+""" % (os.path.join(os.path.dirname(__file__), ".."), os.path.dirname(__file__))
+    env = dict(os.environ, VMV_FUSED_KERNEL="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "fused ok" in r.stdout, r.stderr[-2000:]

@@ -152,6 +152,7 @@ ENV_BLOCKS = {"panda": 5, "baxter": 5}  # (baxter: 0.331 -> 0.307 ms per 1M conf
 # 4x7 0.127, 4x6 0.126, 4x5 0.132, 4x4 0.140, 5x5 0.210 - with chunks of 8 the fourth workgroup did not fit the LDS.
 SELF_BLOCKS = {"panda": 4, "ur5": 3, "baxter": 3}  # (baxter: 0.289 -> 0.227 ms at 3; fetch is faster at 2 than at 3)
 SELF_CHUNK = {"panda": 6}
+FUSED_BLOCKS = {"panda": int(os.environ.get("VMV_FUSED_BLOCKS", 4))}
 for _r in ("panda", "ur5", "fetch", "baxter"):  # tuning knobs: VMV_SELF_BLOCKS_<ROBOT>, VMV_SELF_CHUNK_<ROBOT>
     if f"VMV_SELF_BLOCKS_{_r.upper()}" in os.environ:
         SELF_BLOCKS[_r] = int(os.environ[f"VMV_SELF_BLOCKS_{_r.upper()}"])
@@ -263,16 +264,17 @@ def emit_robot(m):
     L.append("        bool bad = skip || (E.dev->static_hit != 0u);")
     L.append("        // per-wave scratch words live right behind the sphere slab")
     L.append("        const vmv::lds_ptr scratch = slab - __lane_id() + kSlabSpheres * 3 * vmv::kRow;")
-    em = Emitter(m)
     class_radii, link_class = grid_classes(m)
     static = set(static_links(m))
-    for ln in links:
+
+    def emit_env_link(em, ln):
+        """one link of the environment half: FK ops, slab staging, gate, fine chunks (appends to em.lines)"""
         g = env_by_link[ln]
         fine = g["fine"]
         chunks = [fine[i:i + env_chunk] for i in range(0, len(fine), env_chunk)]
         if ln in static:
             em.lines.append(f"        // ---- {ln}: static, evaluated once per environment (static_env_hit)")
-            continue
+            return
         em.lines.append(f"        // ---- {ln}: {len(fine)} spheres")
         em.need([g["bound"]] + fine)
 
@@ -298,6 +300,10 @@ def emit_robot(m):
         em.lines.append("                bad |= gate && vmv::group_any<G>(vmv::env_flag(scratch));")
         em.lines.append("            }")
         em.lines.append("        }")
+
+    em = Emitter(m)
+    for ln in links:
+        emit_env_link(em, ln)
     L += em.lines
     L.append("        return bad;")
     L.append("    }")
@@ -371,6 +377,168 @@ def emit_robot(m):
     L.append("        vmv::lds_u32 *const cand = list + 2 * vmv::kWave + 4;  // A-side candidate word per owner lane")
     L.append(f"        vmv::lds_u32 *const list2 = cand + vmv::kWave;        // item lists: (owner lane | tag << 6), <= {max(CHUNK, SPARSE_BATCH)} * 64 entries")
     L.append(f"        static_assert(vmv::kSelfScratchWords >= 3 * vmv::kWave + 4 + {CHUNK} * vmv::kWave, \"self-collision scratch\");")
+    def emit_self_link(em, ln, bi, batch_set, I):
+        """one B link of the self-collision half (appends to em.lines); groups whose A link is in batch_set"""
+        groups = [sg for sg in self_by_b.get(ln, []) if sg["a"] in batch_set]
+        if not groups:
+            return
+        g_env = env_by_link[ln]
+        fine = g_env["fine"]
+        bb = g_env["bound"]
+        chunks = [fine[i:i + CHUNK] for i in range(0, len(fine), CHUNK)]
+        em.lines.append(f"{I}// ---- B = {ln}: {len(fine)} spheres, {len(groups)} group(s)")
+        for sg in groups:
+            em.need(sorted({p[0] for p in sg["pairs"]}) + [sg["bound_a"]])
+        em.need([bb] + fine)
+        gate_names = []
+        for gi, sg in enumerate(groups):
+            ba = sg["bound_a"]
+            rs = f32(f32(radii[ba]) + f32(radii[bb]))
+            gn = f"gate_{bi}_{links.index(ln)}_{gi}"
+            gate_names.append(gn)
+            em.lines.append(
+                f"{I}const bool {gn} = vmv::group_any<G>(vmv::neg(vmv::sql2_3({em.coord(ba, 0)}, {em.coord(ba, 1)}, "
+                f"{em.coord(ba, 2)}, {em.coord(bb, 0)}, {em.coord(bb, 1)}, {em.coord(bb, 2)}) - {flit(float(f32(rs * rs)))}))"
+                f" && !bad;  // {sg['a']} vs. {ln}")
+        sparse = [gi for gi, sg in enumerate(groups) if id(sg) not in dense_ids]
+        dense = [gi for gi, sg in enumerate(groups) if id(sg) in dense_ids]
+        em.lines.append(f"{I}if (VMV_ABLATE_SELF != 2 && vmv::wave_any(" + " || ".join(gate_names) + "))")
+        em.lines.append(f"{I}{{")
+        em.lines.append(f"{I}    flags[lane] = 0u;")
+        J = I + "    "
+
+        def a_coord(s):
+            cs = []
+            for k in range(3):
+                kind, v = m["outputs"][s][k]
+                cs.append(f"__shfl({em.prefix}{v}, (int) src)" if kind == "op" else flit(v))
+            return cs
+
+        def b_fetch(K, off):
+            em.lines.append(f"{K}const vmv::lds_cptr p = wave_slab + 3 * t * vmv::kRow + src;")
+            em.lines.append(f"{K}const float bx = p[0], by = p[vmv::kRow], bz = p[2 * vmv::kRow];")
+            em.lines.append(f"{K}const float rb = radii[{off} + t];")
+
+        def pair_tests(K, a_sph, acc, guard=None):
+            for ai, s in enumerate(a_sph):
+                cs = a_coord(s)
+                if guard:
+                    em.lines.append(f"{K}if (vmv::wave_any((ma & {1 << ai}u) != 0u))")
+                em.lines.append(f"{K}{{")
+                em.lines.append(f"{K}    const float rs = {flit(radii[s])} + rb;")
+                em.lines.append(f"{K}    {acc} |= vmv::neg(vmv::sql2_3({cs[0]}, {cs[1]}, {cs[2]}, bx, by, bz) - rs * rs);")
+                em.lines.append(f"{K}}}")
+
+        # dense groups: the owners' A-side candidate words (A spheres that reach B's bounding sphere)
+        for gi in dense:
+            sg = groups[gi]
+            a_sph = sorted({p[0] for p in sg["pairs"]})
+            em.lines.append(f"{J}unsigned cand_{gate_names[gi]} = 0u;")
+            em.lines.append(f"{J}if (vmv::wave_any({gate_names[gi]}))")
+            em.lines.append(f"{J}{{")
+            for ai, s in enumerate(a_sph):
+                rs = float(f32(radii[s])) + float(f32(radii[bb])) + SELF_MARGIN
+                em.lines.append(
+                    f"{J}    cand_{gate_names[gi]} |= vmv::neg(vmv::sql2_3({em.coord(s, 0)}, {em.coord(s, 1)}, {em.coord(s, 2)}, "
+                    f"{em.coord(bb, 0)}, {em.coord(bb, 1)}, {em.coord(bb, 2)}) - {flit(float(f32(rs * rs)))}) ? {1 << ai}u : 0u;")
+            em.lines.append(f"{J}}}")
+        done = 0
+        for ci, ch in enumerate(chunks):
+            off = radii_off[ln] + 1 + done
+            for si, s in enumerate(ch):
+                for k in range(3):
+                    em.lines.append(f"{J}slab[{3 * si + k} * vmv::kRow] = {em.coord(s, k)};")
+            em.lines.append(f"{J}vmv::wave_lds_sync();")
+            # the merged entry list holds at most SPARSE_BATCH * 64 (lane, group) entries
+            for sb in range(0, len(sparse), SPARSE_BATCH):
+                batch_groups = sparse[sb:sb + SPARSE_BATCH]
+                em.lines.append(f"{J}if (VMV_ABLATE_SELF != 4 && vmv::wave_any(" + " || ".join(gate_names[gi] for gi in batch_groups) + f"))  // sparse groups, chunk {ci}")
+                em.lines.append(f"{J}{{")
+                K = J + "    "
+                # entries are appended group by group, so entry counts are also item boundaries: the items are
+                # dealt GROUP-MAJOR (all items of group 0, then group 1, ...) and a round of 64 items touches one or
+                # two groups instead of all of them - only those run their A loops
+                em.lines.append(f"{K}int k = 0;")
+                for li, gi in enumerate(batch_groups):
+                    em.lines.append(f"{K}const int kk{li} = k;")
+                    em.lines.append(f"{K}k = vmv::deal_append(list2, k, {gate_names[gi]}, {li}u << 6);  // {groups[gi]['a']}")
+                em.lines.append(f"{K}const int kk{len(batch_groups)} = k;")
+                em.lines.append(f"{K}vmv::wave_lds_sync();")
+                em.lines.append(f"{K}const int items = k * {len(ch)};")
+                for li in range(len(batch_groups)):
+                    em.lines.append(f"{K}const int n{li} = kk{li + 1} - kk{li};")
+                    em.lines.append(f"{K}const float inv{li} = 1.0f / (float) (n{li} > 0 ? n{li} : 1);")
+                em.lines.append(f"{K}for (int base = 0; base < items; base += vmv::kWave)")
+                em.lines.append(f"{K}{{")
+                K2 = K + "    "
+                em.lines.append(f"{K2}const int i = base + (int) lane;")
+                em.lines.append(f"{K2}const bool act = i < items;")
+                em.lines.append(f"{K2}int first = 0, n = n0;")
+                em.lines.append(f"{K2}float inv = inv0;")
+                em.lines.append(f"{K2}unsigned grp = 0u;")
+                for li in range(1, len(batch_groups)):
+                    em.lines.append(f"{K2}if (i >= kk{li} * {len(ch)}) first = kk{li}, n = n{li}, inv = inv{li}, grp = {li}u;")
+                em.lines.append(f"{K2}const int local = i - first * {len(ch)};")
+                em.lines.append(f"{K2}const int t = act ? (int) (((float) local + 0.5f) * inv) : 0;")
+                em.lines.append(f"{K2}const int j = act ? first + (local - t * n) : 0;")
+                em.lines.append(f"{K2}const unsigned e = list2[j];")
+                em.lines.append(f"{K2}const unsigned src = e & 63u;")
+                em.lines.append(f"{K2}grp = act ? grp : ~0u;")
+                b_fetch(K2, off)
+                em.lines.append(f"{K2}bool h = false;")
+                for li, gi in enumerate(batch_groups):
+                    sg = groups[gi]
+                    a_sph = sorted({p[0] for p in sg["pairs"]})
+                    b_sph = sorted({p[1] for p in sg["pairs"]})
+                    assert b_sph == fine and sg["pairs"] == [[s, t] for s in a_sph for t in b_sph]
+                    em.lines.append(f"{K2}if (vmv::wave_any(grp == {li}u))  // {sg['a']} vs. {ln}")
+                    em.lines.append(f"{K2}{{")
+                    em.lines.append(f"{K2}    bool hg = false;")
+                    pair_tests(K2 + "    ", a_sph, "hg")
+                    em.lines.append(f"{K2}    h |= hg && (grp == {li}u);")
+                    em.lines.append(f"{K2}}}")
+                em.lines.append(f"{K2}if (h) flags[src] = 1u;")
+                em.lines.append(f"{K}}}")
+                em.lines.append(f"{K}vmv::wave_lds_sync();")
+                em.lines.append(f"{J}}}")
+            for gi in dense:
+                sg = groups[gi]
+                gn = gate_names[gi]
+                ba = sg["bound_a"]
+                a_sph = sorted({p[0] for p in sg["pairs"]})
+                b_sph = sorted({p[1] for p in sg["pairs"]})
+                assert b_sph == fine and sg["pairs"] == [[s, t] for s in a_sph for t in b_sph]
+                em.lines.append(f"{J}if (vmv::wave_any({gn}))  // dense: {sg['a']} vs. {ln}, chunk {ci}")
+                em.lines.append(f"{J}{{")
+                K = J + "    "
+                em.lines.append(f"{K}cand[lane] = cand_{gn};")
+                em.lines.append(f"{K}int n2 = 0;")
+                for si, s in enumerate(ch):
+                    rs = float(f32(radii[ba])) + SELF_MARGIN + float(f32(radii[s]))
+                    em.lines.append(
+                        f"{K}n2 = vmv::deal_append(list2, n2, {gn} && vmv::neg(vmv::sql2_3({em.coord(ba, 0)}, {em.coord(ba, 1)}, "
+                        f"{em.coord(ba, 2)}, {em.coord(s, 0)}, {em.coord(s, 1)}, {em.coord(s, 2)}) - {flit(float(f32(rs * rs)))}), {si}u << 6);")
+                em.lines.append(f"{K}vmv::wave_lds_sync();")
+                em.lines.append(f"{K}for (int base = 0; base < n2 && VMV_ABLATE_SELF != 1; base += vmv::kWave)")
+                em.lines.append(f"{K}{{")
+                K2 = K + "    "
+                em.lines.append(f"{K2}const int i = base + (int) lane;")
+                em.lines.append(f"{K2}const bool act = i < n2;")
+                em.lines.append(f"{K2}const unsigned e = list2[act ? i : 0];")
+                em.lines.append(f"{K2}const unsigned src = e & 63u;")
+                em.lines.append(f"{K2}const int t = (int) (e >> 6);")
+                b_fetch(K2, off)
+                em.lines.append(f"{K2}const unsigned ma = act ? cand[src] : 0u;")
+                em.lines.append(f"{K2}bool h = false;")
+                pair_tests(K2, a_sph, "h", guard=True)
+                em.lines.append(f"{K2}if (h && act) flags[src] = 1u;")
+                em.lines.append(f"{K}}}")
+                em.lines.append(f"{K}vmv::wave_lds_sync();")
+                em.lines.append(f"{J}}}")
+            done += len(ch)
+        em.lines.append(f"{I}    bad |= vmv::group_any<G>(flags[lane] != 0u);")
+        em.lines.append(f"{I}}}")
+
     for bi, batch in enumerate(batches):
         batch_set = set(batch)
         L.append(f"        {{  // pass {bi}: A in {{{', '.join(batch)}}}")
@@ -386,173 +554,47 @@ def emit_robot(m):
             L.append("            }")
             qn = "qp"
         em = Emitter(m, qname=qn, prefix=f"p{bi}_", indent="            ")
-        I = "            "
         for ln in links:
-            groups = [sg for sg in self_by_b.get(ln, []) if sg["a"] in batch_set]
-            if not groups:
-                continue
-            g_env = env_by_link[ln]
-            fine = g_env["fine"]
-            bb = g_env["bound"]
-            chunks = [fine[i:i + CHUNK] for i in range(0, len(fine), CHUNK)]
-            em.lines.append(f"{I}// ---- B = {ln}: {len(fine)} spheres, {len(groups)} group(s)")
-            for sg in groups:
-                em.need(sorted({p[0] for p in sg["pairs"]}) + [sg["bound_a"]])
-            em.need([bb] + fine)
-            gate_names = []
-            for gi, sg in enumerate(groups):
-                ba = sg["bound_a"]
-                rs = f32(f32(radii[ba]) + f32(radii[bb]))
-                gn = f"gate_{bi}_{links.index(ln)}_{gi}"
-                gate_names.append(gn)
-                em.lines.append(
-                    f"{I}const bool {gn} = vmv::group_any<G>(vmv::neg(vmv::sql2_3({em.coord(ba, 0)}, {em.coord(ba, 1)}, "
-                    f"{em.coord(ba, 2)}, {em.coord(bb, 0)}, {em.coord(bb, 1)}, {em.coord(bb, 2)}) - {flit(float(f32(rs * rs)))}))"
-                    f" && !bad;  // {sg['a']} vs. {ln}")
-            sparse = [gi for gi, sg in enumerate(groups) if id(sg) not in dense_ids]
-            dense = [gi for gi, sg in enumerate(groups) if id(sg) in dense_ids]
-            em.lines.append(f"{I}if (VMV_ABLATE_SELF != 2 && vmv::wave_any(" + " || ".join(gate_names) + "))")
-            em.lines.append(f"{I}{{")
-            em.lines.append(f"{I}    flags[lane] = 0u;")
-            J = I + "    "
-
-            def a_coord(s):
-                cs = []
-                for k in range(3):
-                    kind, v = m["outputs"][s][k]
-                    cs.append(f"__shfl({em.prefix}{v}, (int) src)" if kind == "op" else flit(v))
-                return cs
-
-            def b_fetch(K, off):
-                em.lines.append(f"{K}const vmv::lds_cptr p = wave_slab + 3 * t * vmv::kRow + src;")
-                em.lines.append(f"{K}const float bx = p[0], by = p[vmv::kRow], bz = p[2 * vmv::kRow];")
-                em.lines.append(f"{K}const float rb = radii[{off} + t];")
-
-            def pair_tests(K, a_sph, acc, guard=None):
-                for ai, s in enumerate(a_sph):
-                    cs = a_coord(s)
-                    if guard:
-                        em.lines.append(f"{K}if (vmv::wave_any((ma & {1 << ai}u) != 0u))")
-                    em.lines.append(f"{K}{{")
-                    em.lines.append(f"{K}    const float rs = {flit(radii[s])} + rb;")
-                    em.lines.append(f"{K}    {acc} |= vmv::neg(vmv::sql2_3({cs[0]}, {cs[1]}, {cs[2]}, bx, by, bz) - rs * rs);")
-                    em.lines.append(f"{K}}}")
-
-            # dense groups: the owners' A-side candidate words (A spheres that reach B's bounding sphere)
-            for gi in dense:
-                sg = groups[gi]
-                a_sph = sorted({p[0] for p in sg["pairs"]})
-                em.lines.append(f"{J}unsigned cand_{gate_names[gi]} = 0u;")
-                em.lines.append(f"{J}if (vmv::wave_any({gate_names[gi]}))")
-                em.lines.append(f"{J}{{")
-                for ai, s in enumerate(a_sph):
-                    rs = float(f32(radii[s])) + float(f32(radii[bb])) + SELF_MARGIN
-                    em.lines.append(
-                        f"{J}    cand_{gate_names[gi]} |= vmv::neg(vmv::sql2_3({em.coord(s, 0)}, {em.coord(s, 1)}, {em.coord(s, 2)}, "
-                        f"{em.coord(bb, 0)}, {em.coord(bb, 1)}, {em.coord(bb, 2)}) - {flit(float(f32(rs * rs)))}) ? {1 << ai}u : 0u;")
-                em.lines.append(f"{J}}}")
-            done = 0
-            for ci, ch in enumerate(chunks):
-                off = radii_off[ln] + 1 + done
-                for si, s in enumerate(ch):
-                    for k in range(3):
-                        em.lines.append(f"{J}slab[{3 * si + k} * vmv::kRow] = {em.coord(s, k)};")
-                em.lines.append(f"{J}vmv::wave_lds_sync();")
-                # the merged entry list holds at most SPARSE_BATCH * 64 (lane, group) entries
-                for sb in range(0, len(sparse), SPARSE_BATCH):
-                    batch_groups = sparse[sb:sb + SPARSE_BATCH]
-                    em.lines.append(f"{J}if (VMV_ABLATE_SELF != 4 && vmv::wave_any(" + " || ".join(gate_names[gi] for gi in batch_groups) + f"))  // sparse groups, chunk {ci}")
-                    em.lines.append(f"{J}{{")
-                    K = J + "    "
-                    # entries are appended group by group, so entry counts are also item boundaries: the items are
-                    # dealt GROUP-MAJOR (all items of group 0, then group 1, ...) and a round of 64 items touches one or
-                    # two groups instead of all of them - only those run their A loops
-                    em.lines.append(f"{K}int k = 0;")
-                    for li, gi in enumerate(batch_groups):
-                        em.lines.append(f"{K}const int kk{li} = k;")
-                        em.lines.append(f"{K}k = vmv::deal_append(list2, k, {gate_names[gi]}, {li}u << 6);  // {groups[gi]['a']}")
-                    em.lines.append(f"{K}const int kk{len(batch_groups)} = k;")
-                    em.lines.append(f"{K}vmv::wave_lds_sync();")
-                    em.lines.append(f"{K}const int items = k * {len(ch)};")
-                    for li in range(len(batch_groups)):
-                        em.lines.append(f"{K}const int n{li} = kk{li + 1} - kk{li};")
-                        em.lines.append(f"{K}const float inv{li} = 1.0f / (float) (n{li} > 0 ? n{li} : 1);")
-                    em.lines.append(f"{K}for (int base = 0; base < items; base += vmv::kWave)")
-                    em.lines.append(f"{K}{{")
-                    K2 = K + "    "
-                    em.lines.append(f"{K2}const int i = base + (int) lane;")
-                    em.lines.append(f"{K2}const bool act = i < items;")
-                    em.lines.append(f"{K2}int first = 0, n = n0;")
-                    em.lines.append(f"{K2}float inv = inv0;")
-                    em.lines.append(f"{K2}unsigned grp = 0u;")
-                    for li in range(1, len(batch_groups)):
-                        em.lines.append(f"{K2}if (i >= kk{li} * {len(ch)}) first = kk{li}, n = n{li}, inv = inv{li}, grp = {li}u;")
-                    em.lines.append(f"{K2}const int local = i - first * {len(ch)};")
-                    em.lines.append(f"{K2}const int t = act ? (int) (((float) local + 0.5f) * inv) : 0;")
-                    em.lines.append(f"{K2}const int j = act ? first + (local - t * n) : 0;")
-                    em.lines.append(f"{K2}const unsigned e = list2[j];")
-                    em.lines.append(f"{K2}const unsigned src = e & 63u;")
-                    em.lines.append(f"{K2}grp = act ? grp : ~0u;")
-                    b_fetch(K2, off)
-                    em.lines.append(f"{K2}bool h = false;")
-                    for li, gi in enumerate(batch_groups):
-                        sg = groups[gi]
-                        a_sph = sorted({p[0] for p in sg["pairs"]})
-                        b_sph = sorted({p[1] for p in sg["pairs"]})
-                        assert b_sph == fine and sg["pairs"] == [[s, t] for s in a_sph for t in b_sph]
-                        em.lines.append(f"{K2}if (vmv::wave_any(grp == {li}u))  // {sg['a']} vs. {ln}")
-                        em.lines.append(f"{K2}{{")
-                        em.lines.append(f"{K2}    bool hg = false;")
-                        pair_tests(K2 + "    ", a_sph, "hg")
-                        em.lines.append(f"{K2}    h |= hg && (grp == {li}u);")
-                        em.lines.append(f"{K2}}}")
-                    em.lines.append(f"{K2}if (h) flags[src] = 1u;")
-                    em.lines.append(f"{K}}}")
-                    em.lines.append(f"{K}vmv::wave_lds_sync();")
-                    em.lines.append(f"{J}}}")
-                for gi in dense:
-                    sg = groups[gi]
-                    gn = gate_names[gi]
-                    ba = sg["bound_a"]
-                    a_sph = sorted({p[0] for p in sg["pairs"]})
-                    b_sph = sorted({p[1] for p in sg["pairs"]})
-                    assert b_sph == fine and sg["pairs"] == [[s, t] for s in a_sph for t in b_sph]
-                    em.lines.append(f"{J}if (vmv::wave_any({gn}))  // dense: {sg['a']} vs. {ln}, chunk {ci}")
-                    em.lines.append(f"{J}{{")
-                    K = J + "    "
-                    em.lines.append(f"{K}cand[lane] = cand_{gn};")
-                    em.lines.append(f"{K}int n2 = 0;")
-                    for si, s in enumerate(ch):
-                        rs = float(f32(radii[ba])) + SELF_MARGIN + float(f32(radii[s]))
-                        em.lines.append(
-                            f"{K}n2 = vmv::deal_append(list2, n2, {gn} && vmv::neg(vmv::sql2_3({em.coord(ba, 0)}, {em.coord(ba, 1)}, "
-                            f"{em.coord(ba, 2)}, {em.coord(s, 0)}, {em.coord(s, 1)}, {em.coord(s, 2)}) - {flit(float(f32(rs * rs)))}), {si}u << 6);")
-                    em.lines.append(f"{K}vmv::wave_lds_sync();")
-                    em.lines.append(f"{K}for (int base = 0; base < n2 && VMV_ABLATE_SELF != 1; base += vmv::kWave)")
-                    em.lines.append(f"{K}{{")
-                    K2 = K + "    "
-                    em.lines.append(f"{K2}const int i = base + (int) lane;")
-                    em.lines.append(f"{K2}const bool act = i < n2;")
-                    em.lines.append(f"{K2}const unsigned e = list2[act ? i : 0];")
-                    em.lines.append(f"{K2}const unsigned src = e & 63u;")
-                    em.lines.append(f"{K2}const int t = (int) (e >> 6);")
-                    b_fetch(K2, off)
-                    em.lines.append(f"{K2}const unsigned ma = act ? cand[src] : 0u;")
-                    em.lines.append(f"{K2}bool h = false;")
-                    pair_tests(K2, a_sph, "h", guard=True)
-                    em.lines.append(f"{K2}if (h && act) flags[src] = 1u;")
-                    em.lines.append(f"{K}}}")
-                    em.lines.append(f"{K}vmv::wave_lds_sync();")
-                    em.lines.append(f"{J}}}")
-                done += len(ch)
-            em.lines.append(f"{I}    bad |= vmv::group_any<G>(flags[lane] != 0u);")
-            em.lines.append(f"{I}}}")
+            emit_self_link(em, ln, bi, batch_set, "            ")
         L += em.lines
         L.append("        }")
     L.append("        return bad;")
     L.append("    }")
     L.append(f"    constexpr int kSelfPasses = {len(batches)};")
     L.append("")
+
+    # ---- both halves in one walk of the chain (one FK per configuration) -------------------------------------------
+    # Only for robots whose self-collision half needs a single pass (all A-side spheres fit the registers).
+    fused = len(batches) == 1
+    L.append(f"    constexpr bool kHasFused = {'true' if fused else 'false'};")
+    if fused:
+        L.append("    // Robot::fkcc<rake>, both halves along ONE walk of the chain: a link's FK ops, its environment group")
+        L.append("    // (gate + fine phase through the slab), then the self-collision groups whose B side it is.  The two")
+        L.append("    // halves use the per-wave LDS region one after the other (the environment half's lists are folded")
+        L.append("    // into `bad` before the self-collision half stages its chunk).")
+        L.append("    template <int G, int V>")
+        L.append("    __device__ __forceinline__ bool")
+        L.append("    fkcc_fused(const vmv::EnvView &E, const float (&q)[kDim], vmv::lds_ptr slab, const bool skip)")
+        L.append("    {")
+        L.append("        bool bad = skip || (E.dev->static_hit != 0u);")
+        L.append("        const unsigned lane = __lane_id();")
+        L.append("        const vmv::lds_ptr scratch = slab - lane + kSlabSpheres * 3 * vmv::kRow;")
+        L.append("        const vmv::lds_cptr wave_slab = vmv::uniform((vmv::lds_cptr) (slab - lane));")
+        L.append("        const vmv::lds_cptr radii = vmv::uniform(E.radii);")
+        L.append("        vmv::lds_u32 *const list = (vmv::lds_u32 *) (slab - lane + kSelfSlabSpheres * 3 * vmv::kRow);")
+        L.append("        vmv::lds_u32 *const flags = list + vmv::kWave;")
+        L.append("        vmv::lds_u32 *const cand = list + 2 * vmv::kWave + 4;")
+        L.append("        vmv::lds_u32 *const list2 = cand + vmv::kWave;")
+        em = Emitter(m, prefix="t", indent="        ")
+        bset = set(batches[0])
+        for ln in links:
+            emit_env_link(em, ln)
+            emit_self_link(em, ln, 0, bset, "        ")
+        L += em.lines
+        L.append("        (void) list;")
+        L.append("        return bad;")
+        L.append("    }")
+        L.append("")
 
     # ---- end-effector frame + attachments -----------------------------------------------------------------------
     ee_m = dict(ops=m["ee_ops"], outputs=[m["ee_outputs"][3 * i:3 * i + 3] for i in range(4)])
@@ -703,6 +745,17 @@ def emit_robot(m):
     L.append("    fkcc_env(const vmv::EnvView &E, const float (&q)[kDim], vmv::lds_ptr slab, const bool skip)")
     L.append("    {")
     L.append(f"        return {n}::fkcc_env<G, V>(E, q, slab, skip);")
+    L.append("    }")
+    L.append(f"    static constexpr bool kHasFused = {n}::kHasFused;")
+    L.append(f"    static constexpr int kFusedBlocks = {FUSED_BLOCKS.get(n, 4)};  // workgroups per CU the fused kernel is compiled for")
+    L.append("    template <int G, int V>")
+    L.append("    static __device__ __forceinline__ bool")
+    L.append("    fkcc_fused(const vmv::EnvView &E, const float (&q)[kDim], vmv::lds_ptr slab, const bool skip)")
+    L.append("    {")
+    if len(batches) == 1:
+        L.append(f"        return {n}::fkcc_fused<G, V>(E, q, slab, skip);")
+    else:
+        L.append("        return skip;  // not built for this robot (several self-collision passes): never launched")
     L.append("    }")
     L.append("    template <int G>")
     L.append("    static __device__ __forceinline__ bool")
