@@ -351,3 +351,54 @@ print("fused ok")
     env = dict(os.environ, VMV_FUSED_KERNEL="1")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "fused ok" in r.stdout, r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("cfg", ["config3", "config4", "config5"])
+def test_full_size_baseline_configs(vamp, oracle, cfg):
+    """BASELINE configs 3, 4, 5 at their full sizes (1M Fetch configurations vs a 10k-point CAPT cloud; 1M UR5 edges vs
+    64 primitives; 262,144 Baxter edges vs 32 primitives + a 10k-point CAPT cloud): size-independent properties and
+    sampled oracle parity, on the generators of tools/bench_configs.py."""
+    torch = pytest.importorskip("torch")
+    from envs import build_oracle_env, build_product_env, spec_for
+    from vamp_mvt_amd.workloads import shell_spec
+
+    name, n, edges = {"config3": ("fetch", 1 << 20, False), "config4": ("ur5", 1 << 20, True),
+                      "config5": ("baxter", 1 << 18, True)}[cfg]
+    spec = shell_spec(0) if cfg == "config4" else spec_for(cfg, name)
+    env, oenv = build_product_env(spec), build_oracle_env(oracle, spec)
+    mod = getattr(vamp, name)
+    rid = oracle.robot(name)
+    lo, span = oracle.bounds(rid)
+    rng = np.random.default_rng(case_seed(cfg) % 100000)
+    a = (lo + span * rng.random((n, len(lo)), dtype=np.float32)).astype(np.float32)
+    if edges:  # uniform starts, random directions, lengths as in tools/bench_configs.py
+        d = rng.normal(size=a.shape).astype(np.float32)
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        length = rng.uniform(*((0.2, 1.5) if cfg == "config4" else (0.1, 0.6)), (n, 1)).astype(np.float32)
+        b = (a + d * length).astype(np.float32)
+    ta = torch.from_numpy(a).cuda()
+    tb = torch.from_numpy(b).cuda() if edges else None
+
+    def run(x, y=None):
+        return (mod.validate_motion_batch(x, y, env) if edges else mod.validate_batch(x, env)).cpu().numpy()
+
+    v = run(ta, tb)
+    assert v.shape == (n,) and 0.005 * n < v.sum() < 0.995 * n
+    # permutation equivariance and batch-split invariance: a unit's answer does not depend on its position / wave / rake
+    perm = torch.from_numpy(np.random.default_rng(1).permutation(n)).cuda()
+    assert np.array_equal(run(ta[perm].contiguous(), tb[perm].contiguous() if edges else None), v[perm.cpu().numpy()])
+    lo_i, hi_i = 100003, 100003 + 333333 if n > 500000 else 100003 + 77777
+    assert np.array_equal(run(ta[lo_i:hi_i].contiguous(), tb[lo_i:hi_i].contiguous() if edges else None), v[lo_i:hi_i])
+    # monotonicity: without the environment only self-collisions remain, so nothing valid may become invalid
+    empty = vamp.Environment()
+    free = (mod.validate_motion_batch(ta, tb, empty) if edges else mod.validate_batch(ta, empty)).cpu().numpy()
+    assert not np.any(v & ~free)
+    if edges:  # an edge whose every rake is valid has a valid goal configuration (lane 7 of the first rake is the goal)
+        goal_ok = mod.validate_batch(tb, env).cpu().numpy()
+        assert not np.any(v & ~goal_ok)
+    # sampled oracle parity at full size
+    m = 40000 if cfg == "config3" else (20000 if cfg == "config4" else 4000)
+    idx = np.random.default_rng(2).choice(n, m, replace=False)
+    want = oracle.validate_motion_batch(rid, oenv, a[idx], b[idx], threads=8) if edges else \
+        oracle.validate_batch(rid, oenv, a[idx], threads=8)
+    assert np.array_equal(v[idx], want)
