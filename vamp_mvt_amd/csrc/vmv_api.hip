@@ -1017,6 +1017,46 @@ extern "C"
         return rc;
     }
 
+    // Device staging of the host-buffer entry points: one grow-only arena per (thread, device), so that a planner's many
+    // small calls (one configuration, a handful of edges) do not pay three hipMalloc / hipFree pairs each.
+    namespace
+    {
+        struct StagingArena
+        {
+            void *base = nullptr;
+            size_t capacity = 0;
+            int device = -1;
+            ~StagingArena()
+            {
+                if (base) (void) hipFree(base);  // at thread exit (a no-op error if the runtime is already gone)
+            }
+            void *get(size_t bytes)
+            {
+                int dev = -1;
+                if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+                if (base && (dev != device || bytes > capacity))
+                {
+                    (void) hipFree(base);
+                    base = nullptr;
+                    capacity = 0;
+                }
+                if (!base)
+                {
+                    const size_t want = std::max<size_t>(bytes, 1u << 16);
+                    if (hipMalloc(&base, want) != hipSuccess)
+                    {
+                        base = nullptr;
+                        return nullptr;
+                    }
+                    capacity = want;
+                    device = dev;
+                }
+                return base;
+            }
+        };
+        thread_local StagingArena g_staging;
+    }  // namespace
+
     static int validate_host_common(int robot, const vmv_env *env, const float *a, const float *b, size_t n,
                                     uint64_t *bits)
     {
@@ -1025,22 +1065,17 @@ extern "C"
         if (n == 0) return VMV_OK;
         int rc = require_device();
         if (rc != VMV_OK) return rc;
-        const size_t qb = n * (size_t) kRobots[robot].dimension * 4, wb = ((n + 63) / 64) * 8;
-        float *da = nullptr, *db = nullptr;
-        uint64_t *dbits = nullptr;
-        VMV_HIP(hipMalloc((void **) &da, qb));
-        rc = VMV_OK;
-        if (b && hipMalloc((void **) &db, qb) != hipSuccess) rc = VMV_ERR_HIP;
-        if (rc == VMV_OK && hipMalloc((void **) &dbits, wb) != hipSuccess) rc = VMV_ERR_HIP;
-        if (rc == VMV_OK && hipMemcpy(da, a, qb, hipMemcpyHostToDevice) != hipSuccess) rc = VMV_ERR_HIP;
-        if (rc == VMV_OK && b && hipMemcpy(db, b, qb, hipMemcpyHostToDevice) != hipSuccess) rc = VMV_ERR_HIP;
-        if (rc == VMV_OK)
-            rc = b ? vmv_validate_motion_batch(robot, env, da, db, n, dbits, nullptr) :
-                     vmv_validate_batch(robot, env, da, n, dbits, nullptr);
+        const size_t qb = (n * (size_t) kRobots[robot].dimension * 4 + 255) & ~size_t{255}, wb = ((n + 63) / 64) * 8;
+        char *arena = static_cast<char *>(g_staging.get(2 * qb + wb));
+        if (!arena) return hip_fail(hipErrorOutOfMemory, "staging arena");
+        float *da = reinterpret_cast<float *>(arena), *db = reinterpret_cast<float *>(arena + qb);
+        uint64_t *dbits = reinterpret_cast<uint64_t *>(arena + 2 * qb);
+        const size_t bytes = n * (size_t) kRobots[robot].dimension * 4;
+        if (hipMemcpy(da, a, bytes, hipMemcpyHostToDevice) != hipSuccess) return VMV_ERR_HIP;
+        if (b && hipMemcpy(db, b, bytes, hipMemcpyHostToDevice) != hipSuccess) return VMV_ERR_HIP;
+        rc = b ? vmv_validate_motion_batch(robot, env, da, db, n, dbits, nullptr) :
+                 vmv_validate_batch(robot, env, da, n, dbits, nullptr);
         if (rc == VMV_OK && hipMemcpy(bits, dbits, wb, hipMemcpyDeviceToHost) != hipSuccess) rc = VMV_ERR_HIP;
-        (void) hipFree(da);
-        (void) hipFree(db);
-        (void) hipFree(dbits);
         return rc;
     }
     int vmv_validate_batch_host(int robot, const vmv_env *env, const float *q, size_t n, uint64_t *bits)
