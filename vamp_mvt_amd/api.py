@@ -314,8 +314,7 @@ def install(robot):
         if ok[0] and ok[1:].any():
             n, it = 512, 0
             while n <= min(int(settings.max_samples), 65536) and not res.solved:
-                rng.reset()
-                it += 1
+                it += 1  # each attempt draws the sampler's NEXT n samples (the caller's sampler is never rewound)
                 _, rm = roadmap(start_c, goals, environment, settings, rng, n_samples=n)
                 res.iterations, res.size = it, [len(rm.vertices)]
                 # the extra vertices survive validation in order: start first, then the valid goals
