@@ -92,6 +92,29 @@ class Emitter:
                               f"{op_expr(op, a, b, qname=self.qname, prefix=self.prefix)};")
             self.done[i] = True
 
+    def closure(self, spheres):
+        """every op (emitted or not) the given spheres depend on"""
+        want = set()
+        stack = [v for s in spheres for (kind, v) in self.m["outputs"][s] if kind == "op"]
+        while stack:
+            i = stack.pop()
+            if i in want:
+                continue
+            want.add(i)
+            stack += deps(*self.ops[i])
+        return want
+
+    def emit_ops(self, op_set, indent=None):
+        """emit (in tape order) the not-yet-emitted ops of op_set"""
+        ind = self.indent if indent is None else indent
+        for i in sorted(op_set):
+            if self.done[i]:
+                continue
+            op, a, b = self.ops[i]
+            self.lines.append(f"{ind}const float {self.prefix}{i} = "
+                              f"{op_expr(op, a, b, qname=self.qname, prefix=self.prefix)};")
+            self.done[i] = True
+
     def coord(self, s, k):
         kind, v = self.m["outputs"][s][k]
         return f"{self.prefix}{v}" if kind == "op" else flit(v)
@@ -162,6 +185,7 @@ SELF_DENSE_RATE = float(os.environ.get('VMV_SELF_DENSE_RATE', 0.5))   # groups w
 SELF_DENSE_MIN_A = 3    # ... and whose A side is at least this large use the pre-test + compaction form
 SPARSE_BATCH = 8        # sparse groups merged per item list (the list holds SPARSE_BATCH * 64 entries = CHUNK * 64)
 SELF_MARGIN = 1e-4      # metres; enclosure of fine spheres by bounding spheres is asserted to 2e-6 by tools/robot_trace.py
+LAZY_FINE_FK = os.environ.get("VMV_LAZY_FINE_FK", "1") == "1"  # see emit_env_link
 DEFAULT_CHUNK = 8  # fine spheres staged in the LDS slab at a time (slab = 1 bounding + CHUNK fine spheres per wave)
 assert SPARSE_BATCH <= 8 and DEFAULT_CHUNK <= 8  # vmv::kSelfScratchWords holds 8 * 64 list entries
 
@@ -267,8 +291,11 @@ def emit_robot(m):
     class_radii, link_class = grid_classes(m)
     static = set(static_links(m))
 
-    def emit_env_link(em, ln):
-        """one link of the environment half: FK ops, slab staging, gate, fine chunks (appends to em.lines)"""
+    def emit_env_link(em, ln, lazy=LAZY_FINE_FK):
+        """one link of the environment half: FK ops, slab staging, gate, fine chunks (appends to em.lines).
+        lazy: the FK ops only this link's fine spheres need, and the staging of its first chunk, are emitted inside
+        `if (wave_any(gate))` - links whose bounding sphere never reaches an obstacle (the base links in a shell-shaped
+        scene) then cost their chain ops and one cell lookup, nothing else."""
         g = env_by_link[ln]
         fine = g["fine"]
         chunks = [fine[i:i + env_chunk] for i in range(0, len(fine), env_chunk)]
@@ -276,20 +303,34 @@ def emit_robot(m):
             em.lines.append(f"        // ---- {ln}: static, evaluated once per environment (static_env_hit)")
             return
         em.lines.append(f"        // ---- {ln}: {len(fine)} spheres")
-        em.need([g["bound"]] + fine)
+        private = set()
+        if lazy:
+            later = [s for other in links[links.index(ln) + 1:] if other not in static
+                     for s in [env_by_link[other]["bound"]] + env_by_link[other]["fine"]]
+            em.need([g["bound"]])
+            fine_ops = em.closure(fine)
+            private = fine_ops - em.closure(later)
+            em.emit_ops(fine_ops - private)
+        else:
+            em.need([g["bound"]] + fine)
 
         def stage(slot, s, indent):
             for k in range(3):
                 em.lines.append(f"{indent}slab[{3 * slot + k} * vmv::kRow] = {em.coord(s, k)};")
 
         stage(0, g["bound"], "        ")
-        for si, s in enumerate(chunks[0]):
-            stage(1 + si, s, "        ")
+        if not lazy:
+            for si, s in enumerate(chunks[0]):
+                stage(1 + si, s, "        ")
         em.lines.append("        {")
         em.lines.append(f"            const bool gate = vmv::env_gate<G, Tab, V>(E, slab, scratch, {radii_off[ln]}, {link_class[ln]}, !bad);")
         em.lines.append("            if (VMV_ABLATE_ENV >= 1) bad |= gate;  // measurement aid: no fine phase (wrong answers)")
         em.lines.append("            else if (vmv::wave_any(gate))")
         em.lines.append("            {")
+        if lazy:
+            em.emit_ops(private, indent="                ")
+            for si, s in enumerate(chunks[0]):
+                stage(1 + si, s, "                ")
         done = 0
         for ci, ch in enumerate(chunks):
             if ci > 0:
@@ -588,7 +629,7 @@ def emit_robot(m):
         em = Emitter(m, prefix="t", indent="        ")
         bset = set(batches[0])
         for ln in links:
-            emit_env_link(em, ln)
+            emit_env_link(em, ln, lazy=False)
             emit_self_link(em, ln, 0, bset, "        ")
         L += em.lines
         L.append("        (void) list;")
