@@ -101,6 +101,45 @@ def test_free_spheres_against_the_environment(vamp, oracle, kind):
 
 
 @pytest.mark.parametrize("name", ROBOTS)
+@pytest.mark.parametrize("n_points", [2, 37, 3000, 10000])
+def test_capt_query_copy_changes_no_answer(vamp, oracle, monkeypatch, name, n_points):
+    """The device walks a derived copy of the affordance arrays (each leaf's points sorted by their distance to the
+    leaf's cell, cut per radius bucket: vmv_capt_build.h).  Radii from far below r_min to beyond r_max (the last bucket
+    = the whole list), centres in and around the cloud, duplicated points: the answers must be the oracle's, and the
+    same as with VMV_CAPT_NO_PREFIX=1 (every query walks its leaf's whole list, read at finalize)."""
+    import ctypes
+    from envs import build_oracle_env, build_product_env
+    from vamp_mvt_amd.workloads import POINT_RADIUS, RADII, shell_cloud
+    r_min, r_max = RADII[name]
+    k = 1.6 if name == "baxter" else 1.0
+    pts = shell_cloud(n_points, case_seed("captcopy", name, n_points) % 100000, 0.5 * k, 1.2 * k, 0.0, 1.5)
+    if n_points >= 37:
+        m = min(len(pts[::7]), len(pts[3::7]))
+        pts[::7][:m] = pts[3::7][:m]  # equal points: equal keys in the sort
+    spec = [("capt", (pts, r_min, r_max, POINT_RADIUS))]
+    oenv = build_oracle_env(oracle, spec)
+    rng = np.random.default_rng(case_seed("captcopy-q", name, n_points) % 100000)
+    n = 30000
+    c = pts[rng.integers(len(pts), size=n)] + rng.normal(0, 0.5 * r_max, (n, 3))
+    c[: n // 10] = rng.uniform([-2, -2, -0.5], [2, 2, 2], (n // 10, 3))
+    r = np.concatenate([rng.uniform(0.2 * r_min, r_max, n - 2000), rng.uniform(r_max, 1.6 * r_max, 2000)])
+    s = np.concatenate([c, r[:, None]], 1).astype(np.float32)
+    s[5, 3], s[6, :3] = np.nan, np.inf
+    f = ctypes.POINTER(ctypes.c_float)
+    want = np.array([bool(oracle.L.vo_sphere_environment_in_collision(oenv.h, s[i, :3].ctypes.data_as(f),
+                                                                      ctypes.c_float(float(s[i, 3])))) for i in range(n)])
+    rid, q = uniform_configs(oracle, name, 6000, seed=case_seed("captcopy-cfg", name, n_points) % 100000)
+    want_q = oracle.validate_batch(rid, oenv, q, threads=8)
+    for no_prefix in ("0", "1"):
+        monkeypatch.setenv("VMV_CAPT_NO_PREFIX", no_prefix)
+        env = build_product_env(spec)
+        assert np.array_equal(env.spheres_in_collision(s), want), no_prefix
+        assert np.array_equal(getattr(vamp, name).validate_batch(q, env), want_q), no_prefix
+    if n_points >= 3000:
+        _non_degenerate(want, n)
+
+
+@pytest.mark.parametrize("name", ROBOTS)
 @pytest.mark.parametrize("kind", ["empty", "shell64"])
 def test_clustered_waves_bit_exact(vamp, oracle, name, kind):
     """Adversarial for the kernels' in-wave work lists: every lane of a wave holds (nearly) the same configuration,

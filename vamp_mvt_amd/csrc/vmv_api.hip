@@ -618,6 +618,28 @@ extern "C"
         if (rc != VMV_OK) return rc;
 
         D.n_capt = (uint32_t) env->capts.size();
+        // the query copy of a cloud's affordance arrays (sorted by distance to the leaf cell + per-radius cut table)
+        auto query_copy = [&](const vmv::CaptArrays &a, vmv::CaptDev &c, uint32_t n_vectors) -> int
+        {
+            c.q_x = c.aff_x, c.q_y = c.aff_y, c.q_z = c.aff_z;
+            c.cut = nullptr;
+            c.cut_t0 = c.cut_inv_step = 0.f;
+            if (const char *e = std::getenv("VMV_CAPT_NO_PREFIX"))
+                if (e[0] == '1') return VMV_OK;  // measurement / test aid: every query walks its whole leaf list
+            for (int k = 0; k < 6; ++k)
+                if (!(std::fabs(a.aabb_top[k]) <= 1e3f)) return VMV_OK;  // the 1e-4 m margin is sized for metre-scale clouds
+            vmv::CaptQueryDev q;
+            const int rc = vmv::build_capt_query(c.tests, c.aff_starts, c.aff_x, c.aff_y, c.aff_z, a.nlog2, n_vectors, a.r_min,
+                                                 a.r_max, a.r_point, q);
+            if (rc != VMV_OK) return rc;
+            if (!q.cut) return VMV_OK;
+            env->allocations.push_back(q.points);
+            env->allocations.push_back(q.cut);
+            c.q_x = q.points, c.q_y = q.points + (size_t) n_vectors * 8, c.q_z = q.points + 2 * (size_t) n_vectors * 8;
+            c.cut = q.cut;
+            c.cut_t0 = q.t0, c.cut_inv_step = q.inv_step;
+            return VMV_OK;
+        };
         for (size_t i = 0; i < env->capts.size(); ++i)
         {
             vmv::CaptArrays &a = env->capts[i];
@@ -636,6 +658,7 @@ extern "C"
                 c.r_point = a.r_point;
                 c.nlog2 = a.nlog2;
                 c.n_tests = a.n_tests();
+                if ((rc = query_copy(a, c, (uint32_t) nv)) != VMV_OK) return rc;
                 continue;
             }
             if ((rc = vmv::download_capt(a)) != VMV_OK) return rc;  // built on another device: go through the host
@@ -649,6 +672,7 @@ extern "C"
             c.r_point = a.r_point;
             c.nlog2 = a.nlog2;
             c.n_tests = (uint32_t) a.tests.size();
+            if ((rc = query_copy(a, c, (uint32_t) (a.aff[0].size() / 8))) != VMV_OK) return rc;
         }
         D.capt0_n_tests = D.n_capt ? env->capts[0].n_tests() : 0u;
         D.n_mvt = (uint32_t) env->mvts.size();

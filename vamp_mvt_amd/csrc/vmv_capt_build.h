@@ -226,4 +226,24 @@ namespace vmv
     int build_capt_device(const float *xyz_host, size_t n, float r_min, float r_max, float r_point, CaptArrays &out,
                           uint64_t *device_ns);
     int download_capt(CaptArrays &a);
+
+    // Query copy of the affordance arrays (vmv_capt_gpu.hip, built at vmv_env_finalize from the arrays above, which stay
+    // what inspection returns).  Not part of the reference's structure: it only decides how many of a leaf's vectors a
+    // query has to look at.  A query centre that descends to leaf L lies in L's k-d cell, so |p - c| >= dist(p, cell_L)
+    // for every point p of L's list: the copy holds each leaf's points sorted by that distance (same vector range,
+    // +inf padding last), and `cut[L * kCaptCutBuckets + b]` = how many leading vectors hold a point with
+    // dist(p, cell_L) <= T_b, T_b = t0 + b * step (T of the last bucket = +inf, i.e. the whole list).  A query of radius
+    // r takes the first bucket with T_b >= r + r_point + 1e-4 m and tests those vectors with the reference's predicate;
+    // every point it skips is farther than r + r_point by more than 1e-4 m, five orders of magnitude above fp32 rounding
+    // at metre scale (clouds with coordinates beyond +-1e3 m are walked in full).
+    // (kCaptCutBuckets, kCaptCutMargin: vmv_device.h)
+    struct CaptQueryDev
+    {
+        float *points = nullptr;  // x | y | z, n_vectors * 8 floats each
+        uint16_t *cut = nullptr;  // leaves * kCaptCutBuckets
+        float t0 = 0.f, inv_step = 0.f;
+    };
+    int build_capt_query(const float *d_tests, const uint32_t *d_aff_starts, const float *d_ax, const float *d_ay,
+                         const float *d_az, uint32_t nlog2, uint32_t n_vectors, float r_min, float r_max, float r_point,
+                         CaptQueryDev &out);
 }  // namespace vmv

@@ -558,6 +558,152 @@ int build_capt_device(const float *xyz_host, size_t n, float r_min, float r_max,
     return VMV_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// query copy: per leaf, points sorted by their distance to the leaf's k-d cell + per-radius-bucket vector counts
+// ---------------------------------------------------------------------------------------------------------------------
+namespace
+{
+    // one thread per affordance vector: its leaf (binary search in aff_starts), the leaf's cell (walk up the implicit
+    // tree: node i splits axis depth(i) % 3 at tests[i]; the lo child is 2i + 1), and for each of its 8 points
+    // (leaf << 32 | bits of the distance to the cell, rounded towards zero) as the sort key
+    __global__ void capt_query_keys_kernel(const float *__restrict__ tests, const uint32_t *__restrict__ starts,
+                                           const float *__restrict__ ax, const float *__restrict__ ay, const float *__restrict__ az,
+                                           uint32_t nlog2, uint32_t n_vectors, unsigned long long *__restrict__ keys,
+                                           uint32_t *__restrict__ slots)
+    {
+        const uint32_t v = blockIdx.x * kT + threadIdx.x;
+        if (v >= n_vectors) return;
+        const uint32_t leaves = 1u << nlog2;
+        uint32_t lo_i = 0, hi_i = leaves;  // last leaf with starts[leaf] <= v
+        while (hi_i - lo_i > 1)
+        {
+            const uint32_t mid = (lo_i + hi_i) >> 1;
+            if (starts[mid] <= v)
+                lo_i = mid;
+            else
+                hi_i = mid;
+        }
+        const uint32_t leaf = lo_i;
+        double lo[3] = {-HUGE_VAL, -HUGE_VAL, -HUGE_VAL}, hi[3] = {HUGE_VAL, HUGE_VAL, HUGE_VAL};
+        uint32_t node = leaf + leaves - 1u;
+        for (int depth = (int) nlog2 - 1; depth >= 0; --depth)
+        {
+            const uint32_t parent = (node - 1u) >> 1;
+            const double t = (double) tests[parent];
+            const int k = depth % 3;
+            if (node == 2u * parent + 1u)
+                hi[k] = fmin(hi[k], t);  // lo child: coordinate < plane
+            else
+                lo[k] = fmax(lo[k], t);  // hi child: coordinate >= plane
+            node = parent;
+        }
+        for (int j = 0; j < 8; ++j)
+        {
+            const size_t s = (size_t) v * 8 + j;
+            const double p[3] = {(double) ax[s], (double) ay[s], (double) az[s]};
+            double d2 = 0.0;
+            for (int k = 0; k < 3; ++k)
+            {
+                const double d = fmax(fmax(lo[k] - p[k], p[k] - hi[k]), 0.0);
+                d2 += d * d;
+            }
+            float key = (float) sqrt(d2);
+            if (!(key >= 0.f)) key = 0.f;                                         // NaN input: always tested
+            if (key > 0.f && key < HUGE_VALF && (double) key * (double) key > d2)  // keep it a lower bound
+                key = __uint_as_float(__float_as_uint(key) - 1u);
+            keys[s] = ((unsigned long long) leaf << 32) | (unsigned long long) __float_as_uint(key);
+            slots[s] = (uint32_t) s;
+        }
+    }
+
+    __global__ void capt_query_gather_kernel(const unsigned long long *__restrict__ keys, const uint32_t *__restrict__ slots,
+                                             const float *__restrict__ ax, const float *__restrict__ ay, const float *__restrict__ az,
+                                             size_t n_slots, float *__restrict__ qx, float *__restrict__ qy, float *__restrict__ qz,
+                                             float *__restrict__ vkey)
+    {
+        const size_t s = (size_t) blockIdx.x * kT + threadIdx.x;
+        if (s >= n_slots) return;
+        const uint32_t src = slots[s];
+        qx[s] = ax[src], qy[s] = ay[src], qz[s] = az[src];
+        if ((s & 7u) == 0u) vkey[s >> 3] = __uint_as_float((uint32_t) keys[s]);  // nearest point of the vector
+    }
+
+    // one thread per (leaf, bucket): how many leading vectors of the leaf have their nearest point within T_b
+    __global__ void capt_query_cut_kernel(const uint32_t *__restrict__ starts, const float *__restrict__ vkey, uint32_t leaves,
+                                          float t0, float step, uint16_t *__restrict__ cut, uint32_t *__restrict__ overflow)
+    {
+        const uint32_t i = blockIdx.x * kT + threadIdx.x;
+        if (i >= leaves * (uint32_t) kCaptCutBuckets) return;
+        const uint32_t leaf = i / (uint32_t) kCaptCutBuckets, b = i % (uint32_t) kCaptCutBuckets;
+        const uint32_t s = starts[leaf], e = starts[leaf + 1];
+        uint32_t n = e - s;
+        if (b + 1u < (uint32_t) kCaptCutBuckets)
+        {
+            const float T = t0 + (float) b * step;
+            uint32_t lo = s, hi = e;  // first vector with vkey > T
+            while (lo < hi)
+            {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (vkey[mid] <= T)
+                    lo = mid + 1;
+                else
+                    hi = mid;
+            }
+            n = lo - s;
+        }
+        if (n > 0xffffu) atomicOr(overflow, 1u);
+        cut[i] = (uint16_t) (n > 0xffffu ? 0xffffu : n);
+    }
+}  // namespace
+
+int build_capt_query(const float *d_tests, const uint32_t *d_aff_starts, const float *d_ax, const float *d_ay,
+                     const float *d_az, uint32_t nlog2, uint32_t n_vectors, float r_min, float r_max, float r_point,
+                     CaptQueryDev &out)
+{
+    out = CaptQueryDev{};
+    if (n_vectors == 0 || nlog2 == 0 || nlog2 > 24 || (size_t) n_vectors * 8 >= (size_t{1} << 31)) return VMV_OK;  // nothing to prune
+    if (!(r_max >= r_min) || !std::isfinite(r_max) || !std::isfinite(r_min) || !std::isfinite(r_point)) return VMV_OK;
+    const uint32_t leaves = 1u << nlog2;
+    const size_t n_slots = (size_t) n_vectors * 8;
+    hipStream_t s = nullptr;
+    DevBuf b_keys, b_slots, b_tmp, b_pts, b_vkey, b_cut, b_flag;
+    VMV_C(b_keys.reserve(n_slots * 8 * 2));
+    VMV_C(b_slots.reserve(n_slots * 4 * 2));
+    unsigned long long *keys_a = b_keys.as<unsigned long long>(), *keys_b = keys_a + n_slots;
+    uint32_t *slots_a = b_slots.as<uint32_t>(), *slots_b = slots_a + n_slots;
+    hipLaunchKernelGGL(capt_query_keys_kernel, dim3(nblk(n_vectors)), dim3(kT), 0, s, d_tests, d_aff_starts, d_ax, d_ay, d_az,
+                       nlog2, n_vectors, keys_a, slots_a);
+    size_t sort_bytes = 0;
+    const int end_bit = 32 + (int) nlog2;
+    VMV_C(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, keys_a, keys_b, slots_a, slots_b, (int) n_slots, 0, end_bit, s));
+    VMV_C(b_tmp.reserve(sort_bytes));
+    VMV_C(hipcub::DeviceRadixSort::SortPairs(b_tmp.p, sort_bytes, keys_a, keys_b, slots_a, slots_b, (int) n_slots, 0, end_bit, s));
+    VMV_C(b_pts.reserve(n_slots * 4 * 3 + 64));
+    VMV_C(b_vkey.reserve((size_t) n_vectors * 4));
+    float *qx = b_pts.as<float>(), *qy = qx + n_slots, *qz = qy + n_slots;
+    hipLaunchKernelGGL(capt_query_gather_kernel, dim3(nblk(n_slots)), dim3(kT), 0, s, keys_b, slots_b, d_ax, d_ay, d_az, n_slots, qx,
+                       qy, qz, b_vkey.as<float>());
+    // thresholds: T_b = t0 + b * step for b < B - 1 (T_{B-2} >= r_max + r_point), the last bucket is the whole list
+    const float t0 = r_min + r_point;
+    const float step = std::max((r_max - r_min) / (float) (kCaptCutBuckets - 2), 1e-3f);
+    VMV_C(b_cut.reserve((size_t) leaves * kCaptCutBuckets * 2));
+    VMV_C(b_flag.reserve(4));
+    VMV_C(hipMemsetAsync(b_flag.p, 0, 4, s));
+    hipLaunchKernelGGL(capt_query_cut_kernel, dim3(nblk((size_t) leaves * kCaptCutBuckets)), dim3(kT), 0, s, d_aff_starts,
+                       b_vkey.as<float>(), leaves, t0, step, b_cut.as<uint16_t>(), b_flag.as<uint32_t>());
+    VMV_C(hipGetLastError());
+    uint32_t overflow = 0;
+    VMV_C(hipMemcpy(&overflow, b_flag.p, 4, hipMemcpyDeviceToHost));  // (synchronises)
+    if (overflow) return VMV_OK;  // a leaf with more than 65,535 vectors: no pruning for this cloud
+    out.points = b_pts.as<float>();
+    out.cut = b_cut.as<uint16_t>();
+    b_pts.p = nullptr, b_pts.bytes = 0;
+    b_cut.p = nullptr, b_cut.bytes = 0;
+    out.t0 = t0;
+    out.inv_step = 1.0f / step;
+    return VMV_OK;
+}
+
 int download_capt(CaptArrays &a)
 {
     if (a.host_valid || !a.dev.tests) return VMV_OK;

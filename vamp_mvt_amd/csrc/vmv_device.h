@@ -148,13 +148,21 @@ namespace vmv
         const float *tests;          // 2^nlog2 - 1
         const uint32_t *aff_starts;  // 2^nlog2 + 1
         const float *aabbs;          // 2^nlog2 * 6
-        const float *aff_x, *aff_y, *aff_z;  // n_aff * 8
+        const float *aff_x, *aff_y, *aff_z;  // n_aff * 8 (the reference's layout: what inspection returns)
         float aabb_top[6];
         float r_point;
         uint32_t nlog2, n_tests;
+        // what the query walks (vmv_capt_build.h, CaptQueryDev): the same vector ranges with each leaf's points sorted by
+        // their distance to the leaf's cell, and per (leaf, radius bucket) how many leading vectors can matter.
+        // cut == nullptr: q_* alias aff_* and every query walks its leaf's whole list.
+        const float *q_x, *q_y, *q_z;
+        const uint16_t *cut;
+        float cut_t0, cut_inv_step;
     };
 
     constexpr int kMaxCapt = 4;
+    constexpr int kCaptCutBuckets = 32;       // radius buckets of CaptDev::cut
+    constexpr float kCaptCutMargin = 1e-4f;   // metres
 
     // Multi-level Voxel Table (collision/mvt.hh) as the query reads it: one dense grid of voxel indices (the
     // reference's three pointer levels collapsed; see vmv_mvt_build.h), voxel boxes, compact SoA points.
@@ -350,7 +358,20 @@ namespace vmv
         const gu_cptr starts = (gu_cptr) D->capt[ci].aff_starts;
         uint32_t start = inb ? starts[zi] : 0u;
         uint32_t count = inb ? starts[zi + 1] - start : 0u;
-        const gf_cptr ax = (gf_cptr) D->capt[ci].aff_x, ay = (gf_cptr) D->capt[ci].aff_y, az = (gf_cptr) D->capt[ci].aff_z;
+        // the leaf's points are sorted by their distance to the leaf's cell (a lower bound of their distance to this
+        // centre): only the leading vectors that hold a point within r + r_point (+ 1e-4 m) can hit (vmv_capt_build.h)
+        typedef const uint16_t __attribute__((address_space(1))) *gh_cptr;
+        const gh_cptr cut = (gh_cptr) D->capt[ci].cut;
+        if (cut != nullptr)
+        {
+            const float bf = ((rr + kCaptCutMargin) - D->capt[ci].cut_t0) * D->capt[ci].cut_inv_step;
+            // first bucket whose threshold t0 + b * step exceeds rr + margin; radii beyond the table take the last
+            // bucket = the whole list (also NaN: the comparison below is false)
+            const int b = (bf < (float) (kCaptCutBuckets - 2)) ? max((int) floorf(bf) + 1, 0) : kCaptCutBuckets - 1;
+            const uint32_t c = inb ? (uint32_t) cut[(size_t) zi * kCaptCutBuckets + (uint32_t) b] : 0u;
+            count = min(count, c);
+        }
+        const gf_cptr ax = (gf_cptr) D->capt[ci].q_x, ay = (gf_cptr) D->capt[ci].q_y, az = (gf_cptr) D->capt[ci].q_z;
         // every query tests its own FIRST vector (the leaf's representative point and the first afforded points) before
         // anything is re-dealt: no owner search, and a sphere well inside the cloud usually hits right there - the
         // reference's early exit for the common case
