@@ -618,25 +618,27 @@ extern "C"
         if (rc != VMV_OK) return rc;
 
         D.n_capt = (uint32_t) env->capts.size();
-        // the query copy of a cloud's affordance arrays (sorted by distance to the leaf cell + per-radius cut table)
+        // the query copy of a cloud (blocked planes, leaf records, points sorted by distance to the leaf cell)
         auto query_copy = [&](const vmv::CaptArrays &a, vmv::CaptDev &c, uint32_t n_vectors) -> int
         {
-            c.q_x = c.aff_x, c.q_y = c.aff_y, c.q_z = c.aff_z;
-            c.cut = nullptr;
-            c.cut_t0 = c.cut_inv_step = 0.f;
-            if (const char *e = std::getenv("VMV_CAPT_NO_PREFIX"))
-                if (e[0] == '1') return VMV_OK;  // measurement / test aid: every query walks its whole leaf list
+            bool prune = true;
+            if (const char *e = std::getenv("VMV_CAPT_NO_PREFIX")) prune = e[0] != '1';  // measurement / test aid
             for (int k = 0; k < 6; ++k)
-                if (!(std::fabs(a.aabb_top[k]) <= 1e3f)) return VMV_OK;  // the 1e-4 m margin is sized for metre-scale clouds
+                if (!(std::fabs(a.aabb_top[k]) <= 1e3f)) prune = false;  // the 1e-4 m margin is sized for metre-scale clouds
             vmv::CaptQueryDev q;
-            const int rc = vmv::build_capt_query(c.tests, c.aff_starts, c.aff_x, c.aff_y, c.aff_z, a.nlog2, n_vectors, a.r_min,
-                                                 a.r_max, a.r_point, q);
-            if (rc != VMV_OK) return rc;
-            if (!q.cut) return VMV_OK;
+            const int rc = vmv::build_capt_query(c.tests, c.aff_starts, c.aabbs, c.aff_x, c.aff_y, c.aff_z, a.nlog2, n_vectors,
+                                                 a.r_min, a.r_max, a.r_point, prune, q);
+            if (rc != VMV_OK)
+            {
+                if (rc == VMV_ERR_CAPACITY) g_last_error = "point cloud too large for the device query copy";
+                return rc;
+            }
             env->allocations.push_back(q.points);
-            env->allocations.push_back(q.cut);
+            env->allocations.push_back(q.leaves);
+            env->allocations.push_back(q.planes);
             c.q_x = q.points, c.q_y = q.points + (size_t) n_vectors * 8, c.q_z = q.points + 2 * (size_t) n_vectors * 8;
-            c.cut = q.cut;
+            c.q_leaves = q.leaves;
+            c.q_planes = q.planes;
             c.cut_t0 = q.t0, c.cut_inv_step = q.inv_step;
             return VMV_OK;
         };

@@ -227,23 +227,30 @@ namespace vmv
                           uint64_t *device_ns);
     int download_capt(CaptArrays &a);
 
-    // Query copy of the affordance arrays (vmv_capt_gpu.hip, built at vmv_env_finalize from the arrays above, which stay
-    // what inspection returns).  Not part of the reference's structure: it only decides how many of a leaf's vectors a
-    // query has to look at.  A query centre that descends to leaf L lies in L's k-d cell, so |p - c| >= dist(p, cell_L)
-    // for every point p of L's list: the copy holds each leaf's points sorted by that distance (same vector range,
-    // +inf padding last), and `cut[L * kCaptCutBuckets + b]` = how many leading vectors hold a point with
-    // dist(p, cell_L) <= T_b, T_b = t0 + b * step (T of the last bucket = +inf, i.e. the whole list).  A query of radius
-    // r takes the first bucket with T_b >= r + r_point + 1e-4 m and tests those vectors with the reference's predicate;
-    // every point it skips is farther than r + r_point by more than 1e-4 m, five orders of magnitude above fp32 rounding
-    // at metre scale (clouds with coordinates beyond +-1e3 m are walked in full).
-    // (kCaptCutBuckets, kCaptCutMargin: vmv_device.h)
+    // Query copy of a cloud (vmv_capt_gpu.hip, built at vmv_env_finalize from the arrays above, which stay what inspection
+    // returns).  Not part of the reference's structure — the same planes, boxes and points, laid out for the device walk:
+    //  * points: a query centre that descends to leaf L lies in L's k-d cell, so |p - c| >= dist(p, cell_L) for every point
+    //    p of L's list.  The copy holds each leaf's points sorted by that distance (same vector range, +inf padding
+    //    last) and per (leaf, radius bucket b) how many leading vectors hold a point with dist(p, cell_L) <= T_b,
+    //    T_b = t0 + b * step (the last bucket = the whole list).  A query of radius r takes the first bucket with
+    //    T_b >= r + r_point + 1e-4 m and tests those vectors with the reference's predicate; every point it skips is
+    //    farther than r + r_point by more than 1e-4 m, five orders of magnitude above fp32 rounding at metre scale
+    //    (`prune` = false — VMV_CAPT_NO_PREFIX=1, coordinates beyond +-1e3 m, non-finite radii — keeps the order and
+    //    makes every bucket the whole list);
+    //  * leaves: one 128-byte record per leaf = [box lo xyz, hi xyz | first vector | vector count | 32 x uint16 bucket
+    //    counts (0xffff = whole list) | pad]: one cache line answers the leaf test and says what to walk;
+    //  * planes: the split planes in blocks of 3 tree levels (7 planes + pad = 32 bytes, local heap order; groups of
+    //    levels bottom-aligned, the blocks of a group stored left to right): a descent step fetches one block and
+    //    resolves three levels from registers — five dependent fetches for a 16,384-leaf tree instead of fourteen.
+    // (kCaptCutBuckets, kCaptCutMargin, kCaptLeafWords, capt_plane_slot(): vmv_device.h)
     struct CaptQueryDev
     {
-        float *points = nullptr;  // x | y | z, n_vectors * 8 floats each
-        uint16_t *cut = nullptr;  // leaves * kCaptCutBuckets
+        float *points = nullptr;     // x | y | z, n_vectors * 8 floats each
+        uint32_t *leaves = nullptr;  // 2^nlog2 * kCaptLeafWords
+        float *planes = nullptr;     // blocked copy of `tests` (vmv_device.h: capt_plane_slot)
         float t0 = 0.f, inv_step = 0.f;
     };
-    int build_capt_query(const float *d_tests, const uint32_t *d_aff_starts, const float *d_ax, const float *d_ay,
-                         const float *d_az, uint32_t nlog2, uint32_t n_vectors, float r_min, float r_max, float r_point,
-                         CaptQueryDev &out);
+    int build_capt_query(const float *d_tests, const uint32_t *d_aff_starts, const float *d_aabbs, const float *d_ax,
+                         const float *d_ay, const float *d_az, uint32_t nlog2, uint32_t n_vectors, float r_min, float r_max,
+                         float r_point, bool prune, CaptQueryDev &out);
 }  // namespace vmv

@@ -25,6 +25,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstring>
 #include <limits>
 #include <vector>
 
@@ -628,16 +629,19 @@ namespace
         if ((s & 7u) == 0u) vkey[s >> 3] = __uint_as_float((uint32_t) keys[s]);  // nearest point of the vector
     }
 
-    // one thread per (leaf, bucket): how many leading vectors of the leaf have their nearest point within T_b
-    __global__ void capt_query_cut_kernel(const uint32_t *__restrict__ starts, const float *__restrict__ vkey, uint32_t leaves,
-                                          float t0, float step, uint16_t *__restrict__ cut, uint32_t *__restrict__ overflow)
+    // one thread per (leaf, bucket): how many leading vectors of the leaf have their nearest point within T_b; written
+    // as the uint16 entries of the leaf's record (0xffff = the whole list).  Thread b == 0 also writes the record's head.
+    __global__ void capt_query_leaves_kernel(const uint32_t *__restrict__ starts, const float *__restrict__ aabbs,
+                                             const float *__restrict__ vkey /* nullptr: no pruning */, uint32_t leaves, float t0,
+                                             float step, uint32_t *__restrict__ records)
     {
         const uint32_t i = blockIdx.x * kT + threadIdx.x;
         if (i >= leaves * (uint32_t) kCaptCutBuckets) return;
         const uint32_t leaf = i / (uint32_t) kCaptCutBuckets, b = i % (uint32_t) kCaptCutBuckets;
         const uint32_t s = starts[leaf], e = starts[leaf + 1];
-        uint32_t n = e - s;
-        if (b + 1u < (uint32_t) kCaptCutBuckets)
+        uint32_t *rec = records + (size_t) leaf * kCaptLeafWords;
+        uint32_t n = 0xffffu;
+        if (vkey != nullptr && b + 1u < (uint32_t) kCaptCutBuckets)
         {
             const float T = t0 + (float) b * step;
             uint32_t lo = s, hi = e;  // first vector with vkey > T
@@ -649,56 +653,88 @@ namespace
                 else
                     hi = mid;
             }
-            n = lo - s;
+            n = (lo - s >= 0xffffu) ? 0xffffu : lo - s;
         }
-        if (n > 0xffffu) atomicOr(overflow, 1u);
-        cut[i] = (uint16_t) (n > 0xffffu ? 0xffffu : n);
+        reinterpret_cast<uint16_t *>(rec + 8)[b] = (uint16_t) n;
+        if (b == 0)
+        {
+            for (int k = 0; k < 6; ++k) rec[k] = __float_as_uint(aabbs[(size_t) leaf * 6 + k]);
+            rec[6] = s;
+            rec[7] = e - s;
+            for (int k = 8 + kCaptCutBuckets / 2; k < kCaptLeafWords; ++k) rec[k] = 0u;
+        }
+    }
+
+    __global__ void capt_query_planes_kernel(const float *__restrict__ tests, uint32_t nlog2, uint32_t n_tests,
+                                             float *__restrict__ planes)
+    {
+        const uint32_t i = blockIdx.x * kT + threadIdx.x;
+        if (i >= n_tests) return;
+        const uint32_t l = 31u - (uint32_t) __clz((int) (i + 1u));
+        planes[capt_plane_slot(nlog2, l, i)] = tests[i];
     }
 }  // namespace
 
-int build_capt_query(const float *d_tests, const uint32_t *d_aff_starts, const float *d_ax, const float *d_ay,
-                     const float *d_az, uint32_t nlog2, uint32_t n_vectors, float r_min, float r_max, float r_point,
-                     CaptQueryDev &out)
+int build_capt_query(const float *d_tests, const uint32_t *d_aff_starts, const float *d_aabbs, const float *d_ax,
+                     const float *d_ay, const float *d_az, uint32_t nlog2, uint32_t n_vectors, float r_min, float r_max,
+                     float r_point, bool prune, CaptQueryDev &out)
 {
     out = CaptQueryDev{};
-    if (n_vectors == 0 || nlog2 == 0 || nlog2 > 24 || (size_t) n_vectors * 8 >= (size_t{1} << 31)) return VMV_OK;  // nothing to prune
-    if (!(r_max >= r_min) || !std::isfinite(r_max) || !std::isfinite(r_min) || !std::isfinite(r_point)) return VMV_OK;
-    const uint32_t leaves = 1u << nlog2;
+    if (nlog2 == 0 || nlog2 > 24 || (size_t) n_vectors * 8 >= (size_t{1} << 31)) return VMV_ERR_CAPACITY;
+    if (!(r_max >= r_min) || !std::isfinite(r_max) || !std::isfinite(r_min) || !std::isfinite(r_point)) prune = false;
+    const uint32_t leaves = 1u << nlog2, n_tests = leaves - 1u;
     const size_t n_slots = (size_t) n_vectors * 8;
     hipStream_t s = nullptr;
-    DevBuf b_keys, b_slots, b_tmp, b_pts, b_vkey, b_cut, b_flag;
-    VMV_C(b_keys.reserve(n_slots * 8 * 2));
-    VMV_C(b_slots.reserve(n_slots * 4 * 2));
-    unsigned long long *keys_a = b_keys.as<unsigned long long>(), *keys_b = keys_a + n_slots;
-    uint32_t *slots_a = b_slots.as<uint32_t>(), *slots_b = slots_a + n_slots;
-    hipLaunchKernelGGL(capt_query_keys_kernel, dim3(nblk(n_vectors)), dim3(kT), 0, s, d_tests, d_aff_starts, d_ax, d_ay, d_az,
-                       nlog2, n_vectors, keys_a, slots_a);
-    size_t sort_bytes = 0;
-    const int end_bit = 32 + (int) nlog2;
-    VMV_C(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, keys_a, keys_b, slots_a, slots_b, (int) n_slots, 0, end_bit, s));
-    VMV_C(b_tmp.reserve(sort_bytes));
-    VMV_C(hipcub::DeviceRadixSort::SortPairs(b_tmp.p, sort_bytes, keys_a, keys_b, slots_a, slots_b, (int) n_slots, 0, end_bit, s));
+    DevBuf b_keys, b_slots, b_tmp, b_pts, b_vkey, b_leaves, b_planes;
     VMV_C(b_pts.reserve(n_slots * 4 * 3 + 64));
-    VMV_C(b_vkey.reserve((size_t) n_vectors * 4));
     float *qx = b_pts.as<float>(), *qy = qx + n_slots, *qz = qy + n_slots;
-    hipLaunchKernelGGL(capt_query_gather_kernel, dim3(nblk(n_slots)), dim3(kT), 0, s, keys_b, slots_b, d_ax, d_ay, d_az, n_slots, qx,
-                       qy, qz, b_vkey.as<float>());
+    if (prune && n_slots)
+    {
+        VMV_C(b_keys.reserve(n_slots * 8 * 2));
+        VMV_C(b_slots.reserve(n_slots * 4 * 2));
+        unsigned long long *keys_a = b_keys.as<unsigned long long>(), *keys_b = keys_a + n_slots;
+        uint32_t *slots_a = b_slots.as<uint32_t>(), *slots_b = slots_a + n_slots;
+        hipLaunchKernelGGL(capt_query_keys_kernel, dim3(nblk(n_vectors)), dim3(kT), 0, s, d_tests, d_aff_starts, d_ax, d_ay, d_az,
+                           nlog2, n_vectors, keys_a, slots_a);
+        size_t sort_bytes = 0;
+        const int end_bit = 32 + (int) nlog2;
+        VMV_C(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, keys_a, keys_b, slots_a, slots_b, (int) n_slots, 0, end_bit, s));
+        VMV_C(b_tmp.reserve(sort_bytes));
+        VMV_C(hipcub::DeviceRadixSort::SortPairs(b_tmp.p, sort_bytes, keys_a, keys_b, slots_a, slots_b, (int) n_slots, 0, end_bit, s));
+        VMV_C(b_vkey.reserve((size_t) n_vectors * 4));
+        hipLaunchKernelGGL(capt_query_gather_kernel, dim3(nblk(n_slots)), dim3(kT), 0, s, keys_b, slots_b, d_ax, d_ay, d_az, n_slots,
+                           qx, qy, qz, b_vkey.as<float>());
+    }
+    else if (n_slots)
+    {
+        VMV_C(hipMemcpyAsync(qx, d_ax, n_slots * 4, hipMemcpyDeviceToDevice, s));
+        VMV_C(hipMemcpyAsync(qy, d_ay, n_slots * 4, hipMemcpyDeviceToDevice, s));
+        VMV_C(hipMemcpyAsync(qz, d_az, n_slots * 4, hipMemcpyDeviceToDevice, s));
+    }
     // thresholds: T_b = t0 + b * step for b < B - 1 (T_{B-2} >= r_max + r_point), the last bucket is the whole list
     const float t0 = r_min + r_point;
-    const float step = std::max((r_max - r_min) / (float) (kCaptCutBuckets - 2), 1e-3f);
-    VMV_C(b_cut.reserve((size_t) leaves * kCaptCutBuckets * 2));
-    VMV_C(b_flag.reserve(4));
-    VMV_C(hipMemsetAsync(b_flag.p, 0, 4, s));
-    hipLaunchKernelGGL(capt_query_cut_kernel, dim3(nblk((size_t) leaves * kCaptCutBuckets)), dim3(kT), 0, s, d_aff_starts,
-                       b_vkey.as<float>(), leaves, t0, step, b_cut.as<uint16_t>(), b_flag.as<uint32_t>());
+    const float step = prune ? std::max((r_max - r_min) / (float) (kCaptCutBuckets - 2), 1e-3f) : 1.0f;
+    VMV_C(b_leaves.reserve((size_t) leaves * kCaptLeafWords * 4));
+    hipLaunchKernelGGL(capt_query_leaves_kernel, dim3(nblk((size_t) leaves * kCaptCutBuckets)), dim3(kT), 0, s, d_aff_starts,
+                       d_aabbs, prune && n_slots ? b_vkey.as<float>() : (const float *) nullptr, leaves, t0, step,
+                       b_leaves.as<uint32_t>());
+    // blocked planes (vmv_device.h, capt_plane_slot)
+    const size_t plane_floats = capt_plane_floats(nlog2);
+    VMV_C(b_planes.reserve(plane_floats * 4));
+    VMV_C(hipMemsetAsync(b_planes.p, 0, plane_floats * 4, s));
+    hipLaunchKernelGGL(capt_query_planes_kernel, dim3(nblk(n_tests)), dim3(kT), 0, s, d_tests, nlog2, n_tests, b_planes.as<float>());
     VMV_C(hipGetLastError());
-    uint32_t overflow = 0;
-    VMV_C(hipMemcpy(&overflow, b_flag.p, 4, hipMemcpyDeviceToHost));  // (synchronises)
-    if (overflow) return VMV_OK;  // a leaf with more than 65,535 vectors: no pruning for this cloud
-    out.points = b_pts.as<float>();
-    out.cut = b_cut.as<uint16_t>();
-    b_pts.p = nullptr, b_pts.bytes = 0;
-    b_cut.p = nullptr, b_cut.bytes = 0;
+    VMV_C(hipStreamSynchronize(s));
+    auto release = [](DevBuf &b)
+    {
+        void *p = b.p;
+        b.p = nullptr;
+        b.bytes = 0;
+        return p;
+    };
+    out.points = static_cast<float *>(release(b_pts));
+    out.leaves = static_cast<uint32_t *>(release(b_leaves));
+    out.planes = static_cast<float *>(release(b_planes));
     out.t0 = t0;
     out.inv_step = 1.0f / step;
     return VMV_OK;

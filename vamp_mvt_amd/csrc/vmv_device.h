@@ -145,24 +145,71 @@ namespace vmv
 
     struct CaptDev
     {
+        // what the query walks (vmv_capt_build.h, CaptQueryDev): the planes in 3-level blocks, one 128-byte record per
+        // leaf, and each leaf's points sorted by their distance to the leaf's cell.  Kept together and first: a query
+        // fetches these 22 dwords with a few wide scalar loads.
+        float aabb_top[6];
+        float r_point;
+        uint32_t nlog2;
+        const float *q_planes;
+        const uint32_t *q_leaves;
+        const float *q_x, *q_y, *q_z;
+        uint32_t n_tests;
+        float cut_t0, cut_inv_step;
+        uint32_t pad_;
+        // the reference's layout (what inspection returns; `tests` also feeds the LDS copy of the top levels)
         const float *tests;          // 2^nlog2 - 1
         const uint32_t *aff_starts;  // 2^nlog2 + 1
         const float *aabbs;          // 2^nlog2 * 6
-        const float *aff_x, *aff_y, *aff_z;  // n_aff * 8 (the reference's layout: what inspection returns)
-        float aabb_top[6];
-        float r_point;
-        uint32_t nlog2, n_tests;
-        // what the query walks (vmv_capt_build.h, CaptQueryDev): the same vector ranges with each leaf's points sorted by
-        // their distance to the leaf's cell, and per (leaf, radius bucket) how many leading vectors can matter.
-        // cut == nullptr: q_* alias aff_* and every query walks its leaf's whole list.
-        const float *q_x, *q_y, *q_z;
-        const uint16_t *cut;
-        float cut_t0, cut_inv_step;
+        const float *aff_x, *aff_y, *aff_z;  // n_aff * 8
     };
 
     constexpr int kMaxCapt = 4;
-    constexpr int kCaptCutBuckets = 32;       // radius buckets of CaptDev::cut
+    constexpr int kCaptCutBuckets = 32;       // radius buckets of a leaf record
     constexpr float kCaptCutMargin = 1e-4f;   // metres
+    constexpr int kCaptLeafWords = 32;        // [0..5] box, [6] first vector, [7] vectors, [8..23] 32 x uint16 counts
+    constexpr int kCaptPlaneLevels = 3;       // tree levels per block of CaptDev::q_planes
+    constexpr int kCaptPlaneBlock = 8;        // floats per block: the 7 planes of a 3-level subtree in local heap order
+
+    // The blocked copy of the split planes: the tree's levels are cut into groups of 3, bottom-aligned (the first group
+    // holds nlog2 mod 3 levels when that is not 0), a block is the subtree under one node of the group's first level —
+    // [root | lo child, hi child | their four children | pad] — and the blocks of a group are stored left to right, so
+    // the block number inside its group is the path (one bit per level, 1 = hi side) that leads to its root.  Groups
+    // follow each other from the root down: group g starts at float 8 * (number of blocks before it).
+    __host__ __device__ inline uint32_t capt_group_levels(const uint32_t nlog2, const uint32_t first_level)
+    {
+        const uint32_t s0 = nlog2 % (uint32_t) kCaptPlaneLevels;
+        return (first_level == 0u && s0 != 0u) ? s0 : (uint32_t) kCaptPlaneLevels;
+    }
+    // where plane `i` (heap index, level l = floor(log2(i + 1))) sits: float offset from the start of the copy
+    __host__ __device__ inline uint32_t capt_plane_slot(const uint32_t nlog2, const uint32_t l, const uint32_t i)
+    {
+        uint32_t base = 0u, gs = 0u;  // group that holds level l
+        for (;;)
+        {
+            const uint32_t nl = capt_group_levels(nlog2, gs);
+            if (l < gs + nl) break;
+            base += (uint32_t) kCaptPlaneBlock << gs;
+            gs += nl;
+        }
+        const uint32_t lw = l - gs, t = i + 1u;
+        const uint32_t local1 = (1u << lw) | (t & ((1u << lw) - 1u));
+        const uint32_t block = (t >> lw) - (1u << gs);
+        return base + block * (uint32_t) kCaptPlaneBlock + local1 - 1u;
+    }
+    // floats of the whole copy (limit = nlog2) or of its leading whole groups that fit `budget_floats`
+    __host__ __device__ inline uint32_t capt_plane_floats(const uint32_t nlog2, const uint32_t budget_floats = 0xffffffffu)
+    {
+        uint32_t base = 0u, gs = 0u;
+        while (gs < nlog2)
+        {
+            const uint32_t next = base + ((uint32_t) kCaptPlaneBlock << gs);
+            if (next > budget_floats) break;
+            base = next;
+            gs += capt_group_levels(nlog2, gs);
+        }
+        return base;
+    }
 
     // Multi-level Voxel Table (collision/mvt.hh) as the query reads it: one dense grid of voxel indices (the
     // reference's three pointer levels collapsed; see vmv_mvt_build.h), voxel boxes, compact SoA points.
@@ -235,6 +282,7 @@ namespace vmv
     using cf_cptr = const __attribute__((address_space(4))) float *;
     using gu_cptr = const __attribute__((address_space(1))) uint32_t *;
     typedef __attribute__((address_space(1))) v4f g_v4f;
+    typedef __attribute__((address_space(3))) v4f lds_v4f;
 
     typedef __attribute__((address_space(3))) uint32_t lds_u32;
     // per-workgroup LDS words in front of the radius table: one 64-word hit-flag row per wave for the CAPT walk
@@ -313,6 +361,11 @@ namespace vmv
         return lo < (uint32_t) kWave ? lo : (uint32_t) kWave - 1u;
     }
 
+#ifndef VMV_ABLATE_ENV
+#define VMV_ABLATE_ENV 0  // measurement aid (tools only): 1 = environment kernel without fine phase, 2 = FK only,
+                          // 6 / 7 / 8 / 9 = CAPT query stops after the top box / the descent / the leaf test / the first vector
+#endif
+
     // CAPT::collides_simd (collision/capt.hh:428-512) for the wave's 64 sphere queries (one per lane; the reference's
     // `inbounds.none()` early returns do not change any lane's answer, so lanes are independent queries).
     //   1. per lane: top-AABB test (without r_point, as the reference), nlog2 plane descents (top levels in LDS), leaf
@@ -326,52 +379,95 @@ namespace vmv
     capt_collides(env_cptr D, const uint32_t ci, lds_cptr planes_lds, const uint32_t n_lds, lds_u32 *flags, float x, float y,
                   float z, float r, bool active)
     {
-        // the top levels of the tree are staged in LDS (planes_lds[0 .. n_lds)); deeper planes come through L1/L2
-        const gf_cptr planes = (gf_cptr) D->capt[ci].tests;
-        auto plane = [&](const uint32_t i) -> float { return (i < n_lds) ? planes_lds[i] : planes[i]; };
-        bool inb = active;
-        inb = inb && (x + r >= D->capt[ci].aabb_top[0]) && (x - r <= D->capt[ci].aabb_top[3]);
-        inb = inb && (y + r >= D->capt[ci].aabb_top[1]) && (y - r <= D->capt[ci].aabb_top[4]);
-        inb = inb && (z + r >= D->capt[ci].aabb_top[2]) && (z - r <= D->capt[ci].aabb_top[5]);
-        if (!wave_any(inb)) return false;
-
+        // the cloud's header in one go (a few wide scalar loads, pinned here: left to itself the compiler sinks every
+        // field behind the branch that first needs it, one scalar-cache round trip each)
+        const float t0 = D->capt[ci].aabb_top[0], t1 = D->capt[ci].aabb_top[1], t2 = D->capt[ci].aabb_top[2];
+        const float t3 = D->capt[ci].aabb_top[3], t4 = D->capt[ci].aabb_top[4], t5 = D->capt[ci].aabb_top[5];
+        const float r_point = D->capt[ci].r_point, cut_t0 = D->capt[ci].cut_t0, cut_inv_step = D->capt[ci].cut_inv_step;
         const uint32_t nlog2 = D->capt[ci].nlog2;
-        uint32_t idx = (uint32_t) (x >= plane(0)) + 1u;
-        uint32_t k = 1;
-        for (uint32_t i = 1; i < nlog2; ++i)
-        {
-            const float ck = (k == 0) ? x : (k == 1) ? y : z;
-            idx = (idx << 1) + (uint32_t) (ck >= plane(idx)) + 1u;
-            k = (k == 2) ? 0 : k + 1;
-        }
-        const uint32_t zi = idx - D->capt[ci].n_tests;
-        const float rr = r + D->capt[ci].r_point;
-        const float rc_sq = rr * rr;
-        const gf_cptr bb = (gf_cptr) D->capt[ci].aabbs + 6 * (size_t) zi;
-        const float d0 = x - vclamp(x, bb[0], bb[3]);
-        const float d1 = y - vclamp(y, bb[1], bb[4]);
-        const float d2 = z - vclamp(z, bb[2], bb[5]);
-        const float distsq = d0 * d0 + d1 * d1 + d2 * d2;
-        inb = inb && (distsq <= rc_sq);
-        if (!wave_any(inb)) return false;
+        const gf_cptr bplanes = (gf_cptr) D->capt[ci].q_planes;
+        typedef const uint32_t __attribute__((address_space(1))) *gw_cptr;
+        typedef const uint16_t __attribute__((address_space(1))) *gh_cptr;
+        const gw_cptr leaves = (gw_cptr) D->capt[ci].q_leaves;
+        const gf_cptr ax = (gf_cptr) D->capt[ci].q_x, ay = (gf_cptr) D->capt[ci].q_y, az = (gf_cptr) D->capt[ci].q_z;
+        asm volatile("" ::"s"(t0), "s"(t1), "s"(t2), "s"(t3), "s"(t4), "s"(t5), "s"(r_point), "s"(cut_t0), "s"(cut_inv_step),
+                     "s"(nlog2), "s"(bplanes), "s"(leaves), "s"(ax), "s"(ay), "s"(az));
+        bool inb = active;
+        inb = inb && (x + r >= t0) && (x - r <= t3);
+        inb = inb && (y + r >= t1) && (y - r <= t4);
+        inb = inb && (z + r >= t2) && (z - r <= t5);
+        if (!wave_any(inb) || VMV_ABLATE_ENV == 6) return false;
 
-        const gu_cptr starts = (gu_cptr) D->capt[ci].aff_starts;
-        uint32_t start = inb ? starts[zi] : 0u;
-        uint32_t count = inb ? starts[zi + 1] - start : 0u;
+        // descent through the blocked copy of the planes (capt_plane_slot): three levels per step — one block of 7
+        // planes fetched at once (LDS for the leading groups staged there, n_lds floats; one 32-byte read through
+        // L1 / L2 below), then three compares on values already in registers.  `path` (one bit per level) is the block
+        // number inside the next group and, after the last level, the leaf.
+        uint32_t path = 0u, k = 0u, base = 0u;
+        for (uint32_t gs = 0u; gs < nlog2;)
+        {
+            const uint32_t nl = capt_group_levels(nlog2, gs);
+            const uint32_t next = base + ((uint32_t) kCaptPlaneBlock << gs);
+            v4f pa, pb;
+            if (next <= n_lds)
+            {
+                const lds_v4f *b = (const lds_v4f *) (planes_lds + base + path * (uint32_t) kCaptPlaneBlock);
+                pa = b[0], pb = b[1];
+            }
+            else
+            {
+                const g_v4f *b = (const g_v4f *) (bplanes + base + (size_t) path * kCaptPlaneBlock);
+                pa = b[0], pb = b[1];
+            }
+            const float c0k = (k == 0) ? x : (k == 1) ? y : z;
+            k = (k == 2) ? 0 : k + 1;
+            const bool c0 = c0k >= pa.x;
+            path = (path << 1) | (uint32_t) c0;
+            if (nl >= 2u)
+            {
+                const float c1k = (k == 0) ? x : (k == 1) ? y : z;
+                k = (k == 2) ? 0 : k + 1;
+                const bool c1 = c1k >= (c0 ? pa.z : pa.y);
+                path = (path << 1) | (uint32_t) c1;
+                if (nl >= 3u)
+                {
+                    const float c2k = (k == 0) ? x : (k == 1) ? y : z;
+                    k = (k == 2) ? 0 : k + 1;
+                    const float lo = c1 ? pb.x : pa.w, hi = c1 ? pb.z : pb.y;  // children of the lo child: 3, 4; of the hi child: 5, 6
+                    const bool c2 = c2k >= (c0 ? hi : lo);
+                    path = (path << 1) | (uint32_t) c2;
+                }
+            }
+            base = next;
+            gs += nl;
+        }
+        const uint32_t zi = path;
+        if (VMV_ABLATE_ENV == 7) return zi == 0x12345u;
+        const float rr = r + r_point;
+        const float rc_sq = rr * rr;
+        // the leaf's record: box, first vector, vector count and the bucket counts in one cache line
+        const gw_cptr rec = leaves + (size_t) zi * kCaptLeafWords;
+        const g_v4f *recv = (const g_v4f *) rec;
+        const v4f r0 = recv[0], r1 = recv[1];
         // the leaf's points are sorted by their distance to the leaf's cell (a lower bound of their distance to this
         // centre): only the leading vectors that hold a point within r + r_point (+ 1e-4 m) can hit (vmv_capt_build.h)
-        typedef const uint16_t __attribute__((address_space(1))) *gh_cptr;
-        const gh_cptr cut = (gh_cptr) D->capt[ci].cut;
-        if (cut != nullptr)
-        {
-            const float bf = ((rr + kCaptCutMargin) - D->capt[ci].cut_t0) * D->capt[ci].cut_inv_step;
-            // first bucket whose threshold t0 + b * step exceeds rr + margin; radii beyond the table take the last
-            // bucket = the whole list (also NaN: the comparison below is false)
-            const int b = (bf < (float) (kCaptCutBuckets - 2)) ? max((int) floorf(bf) + 1, 0) : kCaptCutBuckets - 1;
-            const uint32_t c = inb ? (uint32_t) cut[(size_t) zi * kCaptCutBuckets + (uint32_t) b] : 0u;
-            count = min(count, c);
-        }
-        const gf_cptr ax = (gf_cptr) D->capt[ci].q_x, ay = (gf_cptr) D->capt[ci].q_y, az = (gf_cptr) D->capt[ci].q_z;
+        const float bf = ((rr + kCaptCutMargin) - cut_t0) * cut_inv_step;
+        // first bucket whose threshold t0 + b * step exceeds rr + margin; radii beyond the table (and NaN: the
+        // comparison is false) take the last bucket = the whole list
+        const int b = (bf < (float) (kCaptCutBuckets - 2)) ? (int) fmaxf(floorf(bf), -1.0f) + 1 : kCaptCutBuckets - 1;
+        const uint32_t cut = (uint32_t) ((gh_cptr) (rec + 8))[b];
+        const float d0 = x - vclamp(x, r0.x, r0.w);
+        const float d1 = y - vclamp(y, r0.y, r1.x);
+        const float d2 = z - vclamp(z, r0.z, r1.y);
+        const float distsq = d0 * d0 + d1 * d1 + d2 * d2;
+        // (cut == 0: no vector can matter, same answer as walking none; in the condition so that the bucket count is
+        // fetched with the record instead of one memory latency later)
+        inb = inb && (distsq <= rc_sq) && (cut != 0u);
+        if (!wave_any(inb)) return false;
+        if (VMV_ABLATE_ENV == 8) return cut == 0x1234u;
+
+        uint32_t start = inb ? __float_as_uint(r1.z) : 0u;
+        uint32_t count = inb ? __float_as_uint(r1.w) : 0u;
+        count = (cut == 0xffffu) ? count : min(count, cut);
         // every query tests its own FIRST vector (the leaf's representative point and the first afforded points) before
         // anything is re-dealt: no owner search, and a sphere well inside the cloud usually hits right there - the
         // reference's early exit for the common case
@@ -393,7 +489,7 @@ namespace vmv
         }
         start += 1u;
         count = (first_hit || count == 0u) ? 0u : count - 1u;
-        if (!wave_any(count != 0u)) return first_hit;
+        if (!wave_any(count != 0u) || VMV_ABLATE_ENV == 9) return first_hit;
         const uint32_t ends = wave_inclusive_scan(count);
         const uint32_t total = (uint32_t) __builtin_amdgcn_readlane((int) ends, kWave - 1);
         const uint32_t vbase = start - (ends - count);  // vector index of item t of this lane's query = vbase + t
@@ -582,9 +678,6 @@ namespace vmv
 #define VMV_PRIMS_SCALAR 1
 #ifndef VMV_ABLATE_SELF
 #define VMV_ABLATE_SELF 0  // measurement aid (tools only): 1 = no dense pair tests, 2 = gates only, 4 = no sparse groups
-#endif
-#ifndef VMV_ABLATE_ENV
-#define VMV_ABLATE_ENV 0  // measurement aid (tools only): 1 = environment kernel without fine phase, 2 = FK only
 #endif
 #endif
 #if VMV_PRIMS_SCALAR
@@ -1016,7 +1109,7 @@ namespace vmv
         const EnvView E{uniform(E_.dev), uniform(E_.lds), uniform(E_.capt0_planes_in_lds), uniform(E_.radii)};
         lds_u32 *list = (lds_u32 *) uniform((lds_cptr) scratch_);
         lds_u32 *mask_lane = list + 2 * kWave + 4 + lane;
-        if (VMV_ABLATE_ENV >= 2) return slab[0] > 1e30f;  // measurement aid: FK only (keeps the FK results alive)
+        if (VMV_ABLATE_ENV == 2) return slab[0] > 1e30f;  // measurement aid: FK only (keeps the FK results alive)
         bool own;
         if (E.dev->masked_fine && E.dev->grid[0].cells != nullptr)
             own = env_hit_grid<G, V>(E, (uint32_t) uniform(grid_class_), slab[0], slab[kRow], slab[2 * kRow],
