@@ -65,6 +65,7 @@ tot_full_b = tot_pref_b = 0
 BUCKETS = (16, 32, 64)
 t0 = RADII[robot][0] + POINT_RADIUS
 tot_bucket = {B: [0, 0] for B in BUCKETS}
+hist = np.zeros(12, int)
 top = v["aabb_top"]
 for c in q:
     S = o.fk_all(rid, c)
@@ -90,7 +91,10 @@ for c in q:
             step = (RADII[robot][1] - RADII[robot][0]) / (B - 1)
             b = min(max(int(np.floor((rr + 1e-4 - t0) / step)) + 1, 0), B - 1)
             T = np.inf if b == B - 1 else t0 + b * step
-            tot_bucket[B][si >= nf] += int(np.searchsorted(keys_sorted[zi], T, side="right"))
+            c_ = int(np.searchsorted(keys_sorted[zi], T, side="right"))
+            tot_bucket[B][si >= nf] += c_
+            if B == 32:
+                hist[min(c_, 11)] += 1
         if si >= nf:
             tot_full_b += full; tot_pref_b += pref
         else:
@@ -100,3 +104,4 @@ print(f"fine spheres: full {tot_full} prefix {tot_pref} ({tot_pref / max(tot_ful
 for B in BUCKETS:
     print(f"  {B} uniform radius buckets: fine {tot_bucket[B][0]} ({tot_bucket[B][0] / max(tot_full, 1):.3f}) bounding {tot_bucket[B][1]} ({tot_bucket[B][1] / max(tot_full_b, 1):.3f})")
 print(f"bounding    : full {tot_full_b} prefix {tot_pref_b} ({tot_pref_b / max(tot_full_b, 1):.3f})")
+print("prefix histogram (32 buckets; last bin = 11+):", hist.tolist())
