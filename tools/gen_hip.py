@@ -157,14 +157,98 @@ def eval_tape(m, q):
     return out
 
 
-def gate_rates(m, n=4096, seed=0):
-    """Share of uniformly random configurations whose bounding-pair gate fires, per self-collision group."""
+def gate_rates(m, n=4096, seed=0, tables=()):
+    """Share of uniformly random configurations whose bounding-pair gate fires (and whose clearance-table bit, if the
+    group has one, is set), per self-collision group."""
     rng = np.random.default_rng(seed)
     q = np.array(m["lower"]) + np.array(m["span"]) * rng.random((n, m["dimension"]))
     c = eval_tape(m, q)
     r = np.array(m["radii"])
-    return [float((np.linalg.norm(c[:, g["bound_a"]] - c[:, g["bound_b"]], axis=1) < r[g["bound_a"]] + r[g["bound_b"]]).mean())
+    fire = [np.linalg.norm(c[:, g["bound_a"]] - c[:, g["bound_b"]], axis=1) < r[g["bound_a"]] + r[g["bound_b"]]
             for g in m["self_groups"]]
+    for t in tables:
+        N = t["table"].shape[0]
+        (i, j), (loi, loj), (ii, ij) = t["joints"], t["lo"], t["inv"]
+        cell = t["table"][np.clip(((q[:, i] - loi) * ii).astype(int), 0, N - 1), np.clip(((q[:, j] - loj) * ij).astype(int), 0, N - 1)]
+        for bit, gi in enumerate(t["groups"]):
+            fire[gi] = fire[gi] & (((cell >> bit) & 1) != 0)
+    return [float(f.mean()) for f in fire]
+
+
+SELF_TABLE_N = int(os.environ.get("VMV_SELF_TABLE_N", 256))  # cells per joint of the two-joint clearance tables (0: none)
+SELF_TABLE_MARGIN = 1e-4  # metres, on top of the Lipschitz slack of a cell (fp32 effects at metre scale are ~1e-6)
+
+
+def self_tables(m, N=SELF_TABLE_N):
+    """Two-joint clearance tables for the self-collision half.
+
+    The distance of a fine pair (a on link A, b on link B) depends only on the joints between A and B.  For the groups
+    where these are at most two joints (i, j), a table over (q_i, q_j) says for every cell whether the group is
+    CERTAINLY free there: every pair's clearance at the cell centre exceeds what it can lose inside the cell plus
+    SELF_TABLE_MARGIN.  What a pair can lose: |d/dq_i |pb - pa|| <= rho_i = |d(pb - pa)/dq_i| (the lever arm about joint i,
+    measured as the exact chord of a +-h rotation), likewise rho_j; rho of the outer joint is constant, rho of the inner
+    one changes by at most rho_outer * dq_outer inside the cell (both bounds are applied symmetrically, so the order of the
+    joints does not matter); + 10 % and cells taken 1 % larger than they are (fp32 cell index at the borders).  A group
+    whose bit is 0 for a configuration's cell has no colliding fine pair there, so skipping it cannot change the answer;
+    outside the joint bounds (and for NaN) every bit is 1.  -> [dict(joints=(i, j), groups=[index into self_groups...],
+    table=uint8[N][N] (bit g = group g of this table must be tested), lo=(..), inv=(..))]"""
+    if N <= 0:
+        return []
+    dim = m["dimension"]
+    lo, span = np.array(m["lower"], float), np.array(m["span"], float)
+    r = np.array(m["radii"], float)
+    rng = np.random.default_rng(7)
+    q0 = lo + span * rng.random((6, dim))
+    c0 = eval_tape(m, q0)
+    by_joints = {}
+    for gi, g in enumerate(m["self_groups"]):
+        pr = np.array(g["pairs"])
+        d0 = np.linalg.norm(c0[:, pr[:, 0]] - c0[:, pr[:, 1]], axis=2)
+        dep = []
+        for j in range(dim):
+            q1 = q0.copy()
+            q1[:, j] += 0.37 * span[j] * np.where(q1[:, j] - lo[j] < 0.5 * span[j], 1.0, -1.0)
+            c1 = eval_tape(m, q1)
+            if np.abs(np.linalg.norm(c1[:, pr[:, 0]] - c1[:, pr[:, 1]], axis=2) - d0).max() > 1e-9:
+                dep.append(j)
+        if 1 <= len(dep) <= 2:
+            if len(dep) == 1:
+                dep = dep + [dep[0] + 1 if dep[0] + 1 < dim else dep[0] - 1]  # any second joint: constant along it
+            by_joints.setdefault(tuple(sorted(dep)), []).append(gi)
+    out = []
+    h = 1e-3
+    for (i, j), gis in sorted(by_joints.items()):
+        for c in range(0, len(gis), 8):
+            chunk = gis[c:c + 8]
+            qi = lo[i] + span[i] * (np.arange(N) + 0.5) / N
+            qj = lo[j] + span[j] * (np.arange(N) + 0.5) / N
+            Q = np.tile(lo + 0.5 * span, (N * N, 1))
+            Q[:, i] = np.repeat(qi, N)
+            Q[:, j] = np.tile(qj, N)
+            hi_, hj_ = 0.5 * span[i] / N * 1.01, 0.5 * span[j] / N * 1.01
+
+            def shifted(axis, dq):
+                Q2 = Q.copy()
+                Q2[:, axis] += dq
+                return eval_tape(m, Q2)
+            C = eval_tape(m, Q)
+            Cip, Cim, Cjp, Cjm = shifted(i, h), shifted(i, -h), shifted(j, h), shifted(j, -h)
+            table = np.zeros(N * N, np.uint8)
+            shares = []
+            for bit, gi in enumerate(chunk):
+                pr = np.array(m["self_groups"][gi]["pairs"])
+                a, b = pr[:, 0], pr[:, 1]
+                v = C[:, b] - C[:, a]
+                clear = np.linalg.norm(v, axis=2) - r[a] - r[b]
+                rho_i = np.linalg.norm((Cip[:, b] - Cip[:, a]) - (Cim[:, b] - Cim[:, a]), axis=2) / (2 * np.sin(h))
+                rho_j = np.linalg.norm((Cjp[:, b] - Cjp[:, a]) - (Cjm[:, b] - Cjm[:, a]), axis=2) / (2 * np.sin(h))
+                slack = 1.1 * ((rho_i + rho_j * hj_) * hi_ + (rho_j + rho_i * hi_) * hj_) + SELF_TABLE_MARGIN
+                must = (clear <= slack).any(axis=1)
+                table |= (must.astype(np.uint8) << bit)
+                shares.append(1.0 - float(must.mean()))
+            out.append(dict(joints=(i, j), groups=chunk, table=table.reshape(N, N), lo=(float(lo[i]), float(lo[j])),
+                            inv=(N / float(span[i]), N / float(span[j])), free_share=shares))
+    return out
 
 
 SELF_DEAL_MAX_A = 40  # A-side spheres kept in registers for the re-dealt self-collision form
@@ -388,9 +472,37 @@ def emit_robot(m):
         cur_n += link_size[ln]
     if cur:
         batches.append(cur)
-    rates = gate_rates(m)
+    tables = self_tables(m)
+    table_bit = {}  # index into self_groups -> (table number, bit)
+    for ti, t in enumerate(tables):
+        for bit, gi in enumerate(t["groups"]):
+            table_bit[gi] = (ti, bit)
+    group_index = {id(sg): gi for gi, sg in enumerate(m["self_groups"])}
+    rates = gate_rates(m, tables=tables)
     dense_ids = {id(sg) for sg, r in zip(m["self_groups"], rates)
                  if r >= SELF_DENSE_RATE and len({p[0] for p in sg["pairs"]}) >= SELF_DENSE_MIN_A}
+    if tables:
+        L.append("    // Two-joint clearance tables (tools/gen_hip.py: self_tables): bit g of a cell = group g of the table may have a")
+        L.append("    // colliding fine pair somewhere in the cell; 0 = certainly free (every pair's clearance at the cell centre")
+        L.append(f"    // exceeds the Lipschitz slack of the cell + {SELF_TABLE_MARGIN} m).  Outside the joint bounds every bit is 1.")
+        for ti, t in enumerate(tables):
+            N = t["table"].shape[0]
+            names = ", ".join(f"bit {b}: {m['self_groups'][gi]['a']} vs. {m['self_groups'][gi]['b']} ({fs * 100:.1f} % of the cells free)"
+                              for b, (gi, fs) in enumerate(zip(t["groups"], t["free_share"])))
+            L.append(f"    // table {ti}: joints {t['joints'][0]}, {t['joints'][1]}; {names}")
+            L.append(f"    __device__ const unsigned char kSelfTable{ti}[{N} * {N}] = {{")
+            flat = t["table"].reshape(-1)
+            for k in range(0, len(flat), 64):
+                L.append("        " + ",".join(str(int(v)) for v in flat[k:k + 64]) + ",")
+            L.append("    };")
+            L.append(f"    __device__ __forceinline__ unsigned self_table{ti}(const float (&q)[kDim])")
+            L.append("    {")
+            L.append(f"        const float fi = (q[{t['joints'][0]}] - {flit(t['lo'][0])}) * {flit(t['inv'][0])};")
+            L.append(f"        const float fj = (q[{t['joints'][1]}] - {flit(t['lo'][1])}) * {flit(t['inv'][1])};")
+            L.append(f"        const bool in = fi >= 0.0f && fj >= 0.0f && fi < {N}.0f && fj < {N}.0f;  // (false for NaN)")
+            L.append(f"        typedef const unsigned char __attribute__((address_space(1))) *gb_cptr;")
+            L.append(f"        return in ? (unsigned) ((gb_cptr) kSelfTable{ti})[(unsigned) fi * {N}u + (unsigned) fj] : 0xffu;")
+            L.append("    }")
     L.append("    // Self-collision half of Robot::fkcc<rake> (\"robot self-collisions\").")
     L.append("    // Groups (A, B) run when B is the current link; gates (bounding pair) are per lane, exact.")
     L.append("    //  * sparse groups (gate rarely fires): the (passing lane, group) pairs of ALL sparse groups of this B are")
@@ -418,6 +530,8 @@ def emit_robot(m):
     L.append("        vmv::lds_u32 *const cand = list + 2 * vmv::kWave + 4;  // A-side candidate word per owner lane")
     L.append(f"        vmv::lds_u32 *const list2 = cand + vmv::kWave;        // item lists: (owner lane | tag << 6), <= {max(CHUNK, SPARSE_BATCH)} * 64 entries")
     L.append(f"        static_assert(vmv::kSelfScratchWords >= 3 * vmv::kWave + 4 + {CHUNK} * vmv::kWave, \"self-collision scratch\");")
+    for ti in range(len(tables)):
+        L.append(f"        const unsigned tb{ti} = (VMV_ABLATE_SELF == 16) ? 0xffu : self_table{ti}(q);  // issued first: one load, hidden behind FK")
     def emit_self_link(em, ln, bi, batch_set, I):
         """one B link of the self-collision half (appends to em.lines); groups whose A link is in batch_set"""
         groups = [sg for sg in self_by_b.get(ln, []) if sg["a"] in batch_set]
@@ -437,10 +551,12 @@ def emit_robot(m):
             rs = f32(f32(radii[ba]) + f32(radii[bb]))
             gn = f"gate_{bi}_{links.index(ln)}_{gi}"
             gate_names.append(gn)
+            tb = table_bit.get(group_index[id(sg)])
+            tbit = f" && ((tb{tb[0]} >> {tb[1]}) & 1u) != 0u" if tb else ""
             em.lines.append(
                 f"{I}const bool {gn} = vmv::group_any<G>(vmv::neg(vmv::sql2_3({em.coord(ba, 0)}, {em.coord(ba, 1)}, "
-                f"{em.coord(ba, 2)}, {em.coord(bb, 0)}, {em.coord(bb, 1)}, {em.coord(bb, 2)}) - {flit(float(f32(rs * rs)))}))"
-                f" && !bad;  // {sg['a']} vs. {ln}")
+                f"{em.coord(ba, 2)}, {em.coord(bb, 0)}, {em.coord(bb, 1)}, {em.coord(bb, 2)}) - {flit(float(f32(rs * rs)))}){tbit})"
+                f" && !bad{' && VMV_ABLATE_SELF != 8' if id(sg) in dense_ids else ''};  // {sg['a']} vs. {ln}")
         sparse = [gi for gi, sg in enumerate(groups) if id(sg) not in dense_ids]
         dense = [gi for gi, sg in enumerate(groups) if id(sg) in dense_ids]
         em.lines.append(f"{I}if (VMV_ABLATE_SELF != 2 && vmv::wave_any(" + " || ".join(gate_names) + "))")
@@ -626,6 +742,8 @@ def emit_robot(m):
         L.append("        vmv::lds_u32 *const flags = list + vmv::kWave;")
         L.append("        vmv::lds_u32 *const cand = list + 2 * vmv::kWave + 4;")
         L.append("        vmv::lds_u32 *const list2 = cand + vmv::kWave;")
+        for ti in range(len(tables)):
+            L.append(f"        const unsigned tb{ti} = (VMV_ABLATE_SELF == 16) ? 0xffu : self_table{ti}(q);")
         em = Emitter(m, prefix="t", indent="        ")
         bset = set(batches[0])
         for ln in links:

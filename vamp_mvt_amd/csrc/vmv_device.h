@@ -677,7 +677,8 @@ namespace vmv
 #ifndef VMV_PRIMS_SCALAR
 #define VMV_PRIMS_SCALAR 1
 #ifndef VMV_ABLATE_SELF
-#define VMV_ABLATE_SELF 0  // measurement aid (tools only): 1 = no dense pair tests, 2 = gates only, 4 = no sparse groups
+#define VMV_ABLATE_SELF 0  // measurement aid (tools only): 1 = no dense pair tests, 2 = gates only, 4 = no sparse groups, 8 = no dense groups at all,
+                           // 16 = clearance tables ignored (every bit 1; right answers)
 #endif
 #endif
 #if VMV_PRIMS_SCALAR
