@@ -124,9 +124,11 @@ def f32(x):
     return np.float32(x)
 
 
-def eval_tape(m, q):
+def eval_tape(m, q, batch=4096):
     """float64 evaluation of the model's op tape for configurations q[N][dim] -> sphere centres [N][n_total][3]
-    (statistics for code-shape decisions only; the device code evaluates the tape itself)."""
+    (code-shape statistics and the clearance tables; the device code evaluates the tape itself)."""
+    if q.shape[0] > batch:  # keep the intermediates in cache
+        return np.concatenate([eval_tape(m, q[i:i + batch], batch) for i in range(0, q.shape[0], batch)])
     vals = [None] * len(m["ops"])
     for i, (op, a, b) in enumerate(m["ops"]):
         if op == "in":
