@@ -139,6 +139,46 @@ def test_capt_query_copy_changes_no_answer(vamp, oracle, monkeypatch, name, n_po
         _non_degenerate(want, n)
 
 
+@pytest.mark.parametrize("name", ["panda", "ur5", "baxter"])
+def test_reach_certificates_change_no_answer(vamp, oracle, monkeypatch, name):
+    """vmv_env_finalize skips the first links of the chain for environments none of whose primitives they can ever touch
+    (sample centres + slack per link, tools/gen_hip.py: link_samples).  Spheres and cuboids pushed towards the base from
+    far outside until they cross the links' reach — certified, borderline and touching environments — and configurations
+    beyond the joint bounds: the oracle's answers, with the certificates and with VMV_NO_LINK_SKIP=1."""
+    from envs import build_oracle_env, build_product_env
+    from vamp_mvt_amd.workloads import yaw_cuboid
+    rid, q = uniform_configs(oracle, name, 4000, seed=case_seed("reach", name) % 100000)
+    q[::7] = (q[::7] * np.float32(2.3)).astype(np.float32)  # any joint value: the certificates do not assume the bounds
+    z0 = {"panda": 0.33, "ur5": 1.0, "baxter": 0.4}[name]
+    rng = np.random.default_rng(5)
+    some_valid = False
+    for radial in (0.9, 0.6, 0.45, 0.36, 0.31, 0.27, 0.22, 0.15):
+        spec = []
+        for k in range(10):
+            a = rng.uniform(0, 2 * np.pi)
+            c = np.array([radial * np.cos(a), radial * np.sin(a), z0 + rng.uniform(-0.15, 0.15)], np.float32)
+            if name == "baxter":
+                c[:2] += np.array([0.064, -0.259 if k % 2 else 0.259], np.float32)  # around the shoulders
+            if k % 2:
+                spec.append(("sphere", np.array([*c, 0.05], np.float32)))
+            else:
+                spec.append(("cuboid", yaw_cuboid(c, rng.uniform(0, 6.28), np.array([0.05, 0.03, 0.04], np.float32))))
+        oenv = build_oracle_env(oracle, spec)
+        want = oracle.validate_batch(rid, oenv, q, threads=8)
+        some_valid = some_valid or bool(want.any())
+        for off in (None, "1"):
+            if off:
+                monkeypatch.setenv("VMV_NO_LINK_SKIP", off)
+            else:
+                monkeypatch.delenv("VMV_NO_LINK_SKIP", raising=False)
+            env = build_product_env(spec)
+            assert np.array_equal(getattr(vamp, name).validate_batch(q, env), want), (radial, off)
+            a, b = q[:600], (q[:600] + rng.normal(0, 0.2, q[:600].shape)).astype(np.float32)
+            assert np.array_equal(getattr(vamp, name).validate_motion_batch(a, b, env),
+                                  oracle.validate_motion_batch(rid, oenv, a, b, threads=8)), (radial, off)
+    assert some_valid
+
+
 @pytest.mark.parametrize("name", ROBOTS)
 @pytest.mark.parametrize("kind", ["empty", "shell64"])
 def test_clustered_waves_bit_exact(vamp, oracle, name, kind):

@@ -159,6 +159,69 @@ def eval_tape(m, q, batch=4096):
     return out
 
 
+LINK_SAMPLES_N = 48  # samples per joint of the per-link reach certificates
+
+
+def link_samples(m, N=LINK_SAMPLES_N):
+    """Reach certificates for the first links of the chain.  A link whose bounding-sphere centre depends on at most two
+    REVOLUTE joints (found numerically; periodic, so the joint values need no bounds) gets a grid of N x N sample centres
+    over [0, 2 pi)^2 and a slack: every centre the link can ever have lies within `slack` of a sample (lever arms
+    rho = |dc/dq|, exact chords of a +-h rotation, maximum over the samples + 5 %, second-order term as in self_tables).
+    At vmv_env_finalize a link is skipped for an environment when every primitive is farther than
+    bounding radius + slack + 1e-3 m from every sample (vmv_api.hip).  -> {env group index: (samples[n][3], slack)}"""
+    dim = m["dimension"]
+    lo, span = np.array(m["lower"], float), np.array(m["span"], float)
+    rng = np.random.default_rng(11)
+    q0 = lo + span * rng.random((6, dim))
+    c0 = eval_tape(m, q0)
+    out = {}
+    static = set(static_links(m))
+    h = 1e-3
+    for gi, g in enumerate(m["env_groups"]):
+        if g["link"] in static:
+            continue
+        b = g["bound"]
+        dep = []
+        for j in range(dim):
+            q1 = q0.copy()
+            q1[:, j] += 0.37 * span[j] * np.where(q1[:, j] - lo[j] < 0.5 * span[j], 1.0, -1.0)
+            if np.abs(eval_tape(m, q1)[:, b] - c0[:, b]).max() > 1e-9:
+                dep.append(j)
+        if not 1 <= len(dep) <= 2:
+            continue
+        # revolute = periodic with period 2 pi in every dependent joint
+        periodic = True
+        for j in dep:
+            q1 = q0.copy()
+            q1[:, j] += 2 * np.pi
+            periodic = periodic and np.abs(eval_tape(m, q1)[:, b] - c0[:, b]).max() < 1e-9
+        if not periodic:
+            continue
+        if len(dep) == 1:
+            dep = dep + [dep[0]]
+        i, j = dep
+        t = 2 * np.pi * (np.arange(N) + 0.5) / N
+        Q = np.tile(lo + 0.5 * span, (N * N, 1))
+        if i == j:
+            Q = Q[:N]
+            Q[:, i] = t
+        else:
+            Q[:, i] = np.repeat(t, N)
+            Q[:, j] = np.tile(t, N)
+
+        def centres(axis, dq):
+            Q2 = Q.copy()
+            Q2[:, axis] += dq
+            return eval_tape(m, Q2)[:, b]
+        C = eval_tape(m, Q)[:, b]
+        rho_i = np.linalg.norm(centres(i, h) - centres(i, -h), axis=1).max() / (2 * np.sin(h))
+        rho_j = 0.0 if i == j else np.linalg.norm(centres(j, h) - centres(j, -h), axis=1).max() / (2 * np.sin(h))
+        d = np.pi / N * 1.01  # half a cell
+        slack = 1.05 * ((rho_i + rho_j * d) * d + (rho_j + rho_i * d) * d) + 1e-6
+        out[gi] = (C, float(slack))
+    return out
+
+
 def gate_rates(m, n=4096, seed=0, tables=()):
     """Share of uniformly random configurations whose bounding-pair gate fires (and whose clearance-table bit, if the
     group has one, is set), per self-collision group."""
@@ -374,10 +437,12 @@ def emit_robot(m):
     L.append("        bool bad = skip || (E.dev->static_hit != 0u);")
     L.append("        // per-wave scratch words live right behind the sphere slab")
     L.append("        const vmv::lds_ptr scratch = slab - __lane_id() + kSlabSpheres * 3 * vmv::kRow;")
+    L.append("        const unsigned long long skip_links = E.dev->link_skip;  // reach certificates (vmv_api.hip), wave-uniform")
     class_radii, link_class = grid_classes(m)
     static = set(static_links(m))
+    reach = link_samples(m)
 
-    def emit_env_link(em, ln, lazy=LAZY_FINE_FK):
+    def emit_env_link(em, ln, lazy=LAZY_FINE_FK, no_skip=False):
         """one link of the environment half: FK ops, slab staging, gate, fine chunks (appends to em.lines).
         lazy: the FK ops only this link's fine spheres need, and the staging of its first chunk, are emitted inside
         `if (wave_any(gate))` - links whose bounding sphere never reaches an obstacle (the base links in a shell-shaped
@@ -388,7 +453,19 @@ def emit_robot(m):
         if ln in static:
             em.lines.append(f"        // ---- {ln}: static, evaluated once per environment (static_env_hit)")
             return
+        if ln in os.environ.get("VMV_ABLATE_SKIP_LINKS", "").split(","):  # measurement aid (wrong answers)
+            return
         em.lines.append(f"        // ---- {ln}: {len(fine)} spheres")
+        gi_env = m["env_groups"].index(g)
+        guarded = gi_env in reach and not no_skip
+        if guarded:
+            # reach certificate (link_samples): for environments no primitive of which this link can ever touch, the
+            # launcher sets the link's bit and the wave skips its bounding-sphere FK, cell lookup and gate
+            later_all = [s for other in links[links.index(ln) + 1:] if other not in static
+                         for s in [env_by_link[other]["bound"]] + env_by_link[other]["fine"]]
+            em.emit_ops(em.closure([g["bound"]] + fine) & em.closure(later_all))  # what later links need stays outside
+            em.lines.append(f"        if (((skip_links >> {gi_env}) & 1ull) == 0ull)")
+            em.lines.append("        {")
         private = set()
         if lazy:
             later = [s for other in links[links.index(ln) + 1:] if other not in static
@@ -427,6 +504,8 @@ def emit_robot(m):
         em.lines.append("                bad |= gate && vmv::group_any<G>(vmv::env_flag(scratch));")
         em.lines.append("            }")
         em.lines.append("        }")
+        if guarded:
+            em.lines.append("        }")
 
     em = Emitter(m)
     for ln in links:
@@ -749,7 +828,7 @@ def emit_robot(m):
         em = Emitter(m, prefix="t", indent="        ")
         bset = set(batches[0])
         for ln in links:
-            emit_env_link(em, ln, lazy=False)
+            emit_env_link(em, ln, lazy=False, no_skip=True)
             emit_self_link(em, ln, 0, bset, "        ")
         L += em.lines
         L.append("        (void) list;")
@@ -965,6 +1044,15 @@ def main(models):
         pairs = [p for sg in m["self_groups"] for p in sg["pairs"]]
         host.append(f"static const uint16_t kSelfPairs_{m['name']}[{max(len(pairs), 1)}][2] = {{" +
                     ", ".join("{%d, %d}" % (a, b) for a, b in pairs) + "};")
+    # reach certificates of the first links (link_samples): sample centres + slack per link
+    for m in models:
+        reach = link_samples(m)
+        for gi, (C, slack) in reach.items():
+            host.append(f"static const float kReachSamples_{m['name']}_{gi}[{len(C)}][3] = {{" +
+                        ", ".join("{%s, %s, %s}" % (flit(c[0]), flit(c[1]), flit(c[2])) for c in C) + "};")
+        host.append(f"static const vmv_link_reach kReach_{m['name']}[{max(len(reach), 1)}] = {{" +
+                    (", ".join(f"{{{gi}, {len(C)}, {flit(slack)}, {flit(m['radii'][m['env_groups'][gi]['bound']])}, kReachSamples_{m['name']}_{gi}}}"
+                               for gi, (C, slack) in reach.items()) or "{0, 0, 0.0f, 0.0f, nullptr}") + "};")
     host.append("static const vmv_robot_info kRobots[] = {")
     for m in models:
         lo = ", ".join(flit(v) for v in m["lower"] + [0.0] * (16 - m["dimension"]))
@@ -976,7 +1064,7 @@ def main(models):
         host.append(f'    {{"{m["name"]}", {m["dimension"]}, {m["n_spheres"]}, {m["resolution"]}, '
                     f'{flit(m["min_radius"])}, {flit(m["max_radius"])}, {flit(max_bound)}, {{{gr}}}, {{{lo}}}, {{{sp}}}, {{{ds}}}, '
                     f'"{m["end_effector"]}", {{{jn}}}, {sum(len(sg["pairs"]) for sg in m["self_groups"])}, '
-                    f'kSelfPairs_{m["name"]}}},')
+                    f'kSelfPairs_{m["name"]}, {len(link_samples(m))}, kReach_{m["name"]}}},')
     host.append("};")
     host.append(f"static const int kNumRobots = {len(models)};")
     with open(os.path.join(d, "robots_host.inc"), "w") as f:

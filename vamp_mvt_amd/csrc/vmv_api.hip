@@ -24,6 +24,14 @@
 // ---------------------------------------------------------------------------------------------------------
 // host-side robot table
 // ---------------------------------------------------------------------------------------------------------
+struct vmv_link_reach  // reach certificate of one link (tools/gen_hip.py: link_samples)
+{
+    int group;       // index of the link's environment group = bit in EnvDev::link_skip
+    int n;           // sample centres
+    float slack;     // every centre the link can have lies within `slack` of a sample
+    float radius;    // the link's bounding-sphere radius
+    const float (*samples)[3];
+};
 struct vmv_robot_info
 {
     const char *name;
@@ -35,6 +43,8 @@ struct vmv_robot_info
     const char *joint_names[16];
     int n_self_pairs;
     const uint16_t (*self_pairs)[2];  // fine pairs of the self-collision groups, in group order
+    int n_reach;
+    const vmv_link_reach *reach;
 };
 #include "gen/robots_host.inc"
 
@@ -840,6 +850,42 @@ namespace
                 Dr.grid_words = env->grid_words;
             }
         }
+        // Reach certificates: a link whose bounding sphere cannot come within 1 mm of any primitive, whatever the
+        // configuration, is skipped by the environment kernels (its gate could never fire).  Only for environments of
+        // well-formed primitives (masked_fine: the distance expressions below are then exact and 1-Lipschitz) without
+        // heightfields / point clouds; VMV_NO_LINK_SKIP=1 switches it off (A/B, tests).
+        Dr.link_skip = 0ull;
+        if (Dr.masked_fine && Dr.n_capt + Dr.n_mvt + Dr.n_heightfield == 0 && std::getenv("VMV_NO_LINK_SKIP") == nullptr)
+            for (int k = 0; k < kRobots[r].n_reach; ++k)
+            {
+                const vmv_link_reach &lr = kRobots[r].reach[k];
+                if (lr.n <= 0 || lr.group < 0 || lr.group >= 64) continue;
+                const double need = (double) lr.radius + (double) lr.slack + 1e-3;
+                bool free = true;
+                for (int i = 0; i < lr.n && free; ++i)
+                {
+                    const double x[3] = {lr.samples[i][0], lr.samples[i][1], lr.samples[i][2]};
+                    for (const auto &g : env->grid_prims)
+                    {
+                        double lip = 1.0, d;
+                        if (g.type == 0)
+                        {
+                            const double dx = x[0] - g.p[0], dy = x[1] - g.p[1], dz = x[2] - g.p[2];
+                            d = std::sqrt(dx * dx + dy * dy + dz * dz) - g.p[3];
+                        }
+                        else if (g.type <= 2)
+                            d = vmv::grid_detail::capsule_g(g.p, x, g.type == 2, lip);
+                        else
+                            d = vmv::grid_detail::cuboid_g(g.p, x, g.type == 4, lip);
+                        if (!(d > need * lip))
+                        {
+                            free = false;
+                            break;
+                        }
+                    }
+                }
+                if (free) Dr.link_skip |= 1ull << lr.group;
+            }
         env->launch[r].host = Dr;
         std::vector<vmv::EnvDev> one(1, Dr);
         const vmv::EnvDev *d_env = nullptr;

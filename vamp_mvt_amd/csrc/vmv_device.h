@@ -260,6 +260,7 @@ namespace vmv
         // "some static link of the robot (its spheres do not depend on the configuration) collides with this
         // environment": evaluated once per (environment, robot) by static_links_kernel with the same device functions
         uint32_t static_hit;
+        unsigned long long link_skip;  // bit g: environment group g can never touch this environment (reach certificates)
         uint32_t n_capt;
         uint32_t capt0_n_tests;  // size of capt[0].tests (candidate for LDS staging behind the primitive block)
         uint32_t n_mvt;
