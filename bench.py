@@ -130,6 +130,8 @@ def main():
     ap.add_argument("--configs", type=int, default=CONFIGS_PER_GPU, help="configurations per GPU per step (weak) and "
                     "per job per step (strong)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-two-streams", action="store_true",
+                    help="skip the informational two-stream leg (profiling runs: its overlapping launches would mix into the per-kernel averages)")
     ap.add_argument("--cpu-sample", type=int, default=1 << 21)
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="development only: run the N-rank control flow with every rank on cuda:0 and the exchange "
@@ -274,7 +276,7 @@ def main():
 
     # ---- informational: independent batches on two streams (N = 1 only; never `value`) ------------------------------
     two_streams = None
-    if world == 1:
+    if world == 1 and not args.no_two_streams:
         # the same job with consecutive steps submitted on alternating streams (each step = one vmv_validate_batch call
         # over the whole batch, its own result buffer): the next step's kernels fill the tail of the previous step's
         side = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
