@@ -139,6 +139,25 @@ def test_capt_query_copy_changes_no_answer(vamp, oracle, monkeypatch, name, n_po
         _non_degenerate(want, n)
 
 
+@pytest.mark.parametrize("name", ROBOTS)
+@pytest.mark.parametrize("kind", ["shell64", "cage", "capt", "attach", "empty"])
+def test_listed_self_collision_kernel_is_bit_exact(vamp, oracle, monkeypatch, name, kind):
+    """Opt-in path of vmv_validate_batch (VMV_COMPACT=1; vmv_validate_batch_env_ws / _self_ws): the environment kernel
+    lists the configurations it leaves valid, the self-collision kernel runs for those only and clears the bits of
+    colliding ones.  Forced on for small batches here (VMV_COMPACT_MIN), ragged sizes included; the answers are the
+    oracle's, and the plain two kernels'."""
+    env, oenv = make_env(kind, oracle, name)
+    for n in (1, 63, 64, 65, 4097, 20000):
+        rid, q = uniform_configs(oracle, name, n, seed=case_seed(name, kind, "listed", n) % 100000)
+        q[::13] = (q[::13] * np.float32(1.6)).astype(np.float32)
+        want = oracle.validate_batch(rid, oenv, q, threads=8)
+        monkeypatch.setenv("VMV_COMPACT_MIN", "1")
+        monkeypatch.setenv("VMV_COMPACT", "1")
+        assert np.array_equal(getattr(vamp, name).validate_batch(q, env), want), n
+        monkeypatch.delenv("VMV_COMPACT")
+        assert np.array_equal(getattr(vamp, name).validate_batch(q, env), want), n
+
+
 @pytest.mark.parametrize("name", ["panda", "ur5", "baxter"])
 def test_reach_certificates_change_no_answer(vamp, oracle, monkeypatch, name):
     """vmv_env_finalize skips the first links of the chain for environments none of whose primitives they can ever touch
