@@ -148,15 +148,6 @@ int vmv_validate_batch(int robot, const vmv_env *env, const float *d_q, size_t n
  * into words already written.  vmv_validate_batch == _env then _self on the same stream. */
 int vmv_validate_batch_env(int robot, const vmv_env *env, const float *d_q, size_t n, uint64_t *d_bits, void *stream);
 int vmv_validate_batch_self(int robot, const float *d_q, size_t n, uint64_t *d_bits, void *stream);
-/* The same two stages with a hand-over list: the environment kernel also lists the configurations it leaves valid in
- * `d_ws` (vmv_validate_workspace_bytes(n) bytes of device memory, contents irrelevant), and the self-collision kernel runs
- * forward kinematics for the listed ones only and clears the bit of a colliding one.  Same answers as the pair above;
- * faster where few configurations survive the environment half, slower where most do, so
- * vmv_validate_batch uses it only with VMV_COMPACT=1 in the environment. */
-size_t vmv_validate_workspace_bytes(size_t n);
-int vmv_validate_batch_env_ws(int robot, const vmv_env *env, const float *d_q, size_t n, uint64_t *d_bits, void *d_ws,
-                              void *stream);
-int vmv_validate_batch_self_ws(int robot, const float *d_q, size_t n, uint64_t *d_bits, const void *d_ws, void *stream);
 /* validate_motion<Robot, 8, Robot::resolution>(start, goal, env) — planning/validate.hh:24-77, the call every
  * planner makes per edge (rrtc.hh:136-140, prm.hh:59, fcit.hh:238 ...).  One bit per edge. */
 int vmv_validate_motion_batch(int robot, const vmv_env *env, const float *d_start, const float *d_goal, size_t n,

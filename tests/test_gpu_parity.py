@@ -141,20 +141,19 @@ def test_capt_query_copy_changes_no_answer(vamp, oracle, monkeypatch, name, n_po
 
 @pytest.mark.parametrize("name", ROBOTS)
 @pytest.mark.parametrize("kind", ["shell64", "cage", "capt", "attach", "empty"])
-def test_listed_self_collision_kernel_is_bit_exact(vamp, oracle, monkeypatch, name, kind):
-    """Opt-in path of vmv_validate_batch (VMV_COMPACT=1; vmv_validate_batch_env_ws / _self_ws): the environment kernel
-    lists the configurations it leaves valid, the self-collision kernel runs for those only and clears the bits of
-    colliding ones.  Forced on for small batches here (VMV_COMPACT_MIN), ragged sizes included; the answers are the
-    oracle's, and the plain two kernels'."""
+def test_grouped_self_collision_kernel_is_bit_exact(vamp, oracle, monkeypatch, name, kind):
+    """The self-collision kernel gives every wave 1..8 validity words and works through the configurations still valid in
+    them, 64 per pass (the launcher picks the group size from the batch size; VMV_SELF_GROUP forces it here).  Ragged
+    sizes, every group size: the oracle's answers."""
     env, oenv = make_env(kind, oracle, name)
     for n in (1, 63, 64, 65, 4097, 20000):
-        rid, q = uniform_configs(oracle, name, n, seed=case_seed(name, kind, "listed", n) % 100000)
+        rid, q = uniform_configs(oracle, name, n, seed=case_seed(name, kind, "grouped", n) % 100000)
         q[::13] = (q[::13] * np.float32(1.6)).astype(np.float32)
         want = oracle.validate_batch(rid, oenv, q, threads=8)
-        monkeypatch.setenv("VMV_COMPACT_MIN", "1")
-        monkeypatch.setenv("VMV_COMPACT", "1")
-        assert np.array_equal(getattr(vamp, name).validate_batch(q, env), want), n
-        monkeypatch.delenv("VMV_COMPACT")
+        for group in ("1", "2", "3", "5", "8"):
+            monkeypatch.setenv("VMV_SELF_GROUP", group)
+            assert np.array_equal(getattr(vamp, name).validate_batch(q, env), want), (n, group)
+        monkeypatch.delenv("VMV_SELF_GROUP")
         assert np.array_equal(getattr(vamp, name).validate_batch(q, env), want), n
 
 

@@ -96,9 +96,6 @@ def _load():
         "vmv_validate_batch": (I, [I, V, V, S, V, V]),
         "vmv_validate_batch_env": (I, [I, V, V, S, V, V]),
         "vmv_validate_batch_self": (I, [I, V, S, V, V]),
-        "vmv_validate_workspace_bytes": (S, [S]),
-        "vmv_validate_batch_env_ws": (I, [I, V, V, S, V, V, V]),
-        "vmv_validate_batch_self_ws": (I, [I, V, S, V, V, V]),
         "vmv_validate_motion_batch": (I, [I, V, V, V, S, V, V]),
         "vmv_fk_batch_host": (I, [I, c_float_p, S, c_float_p]),
         "vmv_eefk_batch": (I, [I, V, S, V, V]),

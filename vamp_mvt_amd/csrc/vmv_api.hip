@@ -50,7 +50,6 @@ struct vmv_robot_info
 
 namespace
 {
-    constexpr size_t kCompactMinBatch = size_t{1} << 17;  // vmv_validate_batch lists the valid configurations from here on
     thread_local std::string g_last_error;
 
     int hip_fail(hipError_t e, const char *what)
@@ -940,50 +939,7 @@ extern "C"
         if (n == 0) return VMV_OK;
         if (int rc = check_device(env); rc != VMV_OK) return rc;
         if (int rc = ensure_robot(env, robot); rc != VMV_OK) return rc;
-        // Opt-in (VMV_COMPACT=1; the _ws entry points below are the explicit form): the environment kernel lists the
-        // configurations it leaves valid and the self-collision kernel runs for those only (stream-ordered scratch).
-        // It pays where few configurations survive the environment half (1M Baxter configurations in the 64-primitive
-        // scene, 3 % valid: 0.51 -> 0.36 ms; Fetch, 46 %: 0.356 -> 0.333) and costs where most do (Panda, 62.5 %:
-        // 0.240 -> 0.252: one memory-side atomic per wave in the environment kernel, gathered configuration rows in
-        // the self-collision kernel), so the default stays the plain pair.
-        hipStream_t s = static_cast<hipStream_t>(stream);
-        const char *opt = std::getenv("VMV_COMPACT");
-        const bool compact = opt != nullptr && opt[0] == '1';
-        size_t min_batch = kCompactMinBatch;
-        if (const char *e = std::getenv("VMV_COMPACT_MIN")) min_batch = (size_t) std::strtoull(e, nullptr, 10);  // tests
-        void *ws = nullptr;
-        if (compact && n >= min_batch && n < (size_t{1} << 32) && hipMallocAsync(&ws, vmv::validate_ws_bytes(n), s) != hipSuccess)
-        {
-            (void) hipGetLastError();
-            ws = nullptr;
-        }
-        const int rc = kLaunchers[robot]->validate(env->launch[robot], d_q, n, d_bits, s, 7, static_cast<uint32_t *>(ws));
-        if (ws) (void) hipFreeAsync(ws, s);
-        return rc;
-    }
-
-    size_t vmv_validate_workspace_bytes(size_t n) { return vmv::validate_ws_bytes(n); }
-
-    int vmv_validate_batch_env_ws(int robot, const vmv_env *env, const float *d_q, size_t n, uint64_t *d_bits, void *d_ws,
-                                  void *stream)
-    {
-        if (!robot_ok(robot)) return VMV_ERR_UNKNOWN_ROBOT;
-        if (!env || !d_q || !d_bits || !d_ws || n >= (size_t{1} << 32)) return VMV_ERR_INVALID_ARGUMENT;
-        if (!env->finalized) return VMV_ERR_NOT_FINALIZED;
-        if (n == 0) return VMV_OK;
-        if (int rc = check_device(env); rc != VMV_OK) return rc;
-        if (int rc = ensure_robot(env, robot); rc != VMV_OK) return rc;
-        return kLaunchers[robot]->validate(env->launch[robot], d_q, n, d_bits, static_cast<hipStream_t>(stream), 1,
-                                           static_cast<uint32_t *>(d_ws));
-    }
-
-    int vmv_validate_batch_self_ws(int robot, const float *d_q, size_t n, uint64_t *d_bits, const void *d_ws, void *stream)
-    {
-        if (!robot_ok(robot)) return VMV_ERR_UNKNOWN_ROBOT;
-        if (!d_q || !d_bits || !d_ws || n >= (size_t{1} << 32)) return VMV_ERR_INVALID_ARGUMENT;
-        if (n == 0) return VMV_OK;
-        return kLaunchers[robot]->validate(vmv::EnvLaunch{}, d_q, n, d_bits, static_cast<hipStream_t>(stream), 2,
-                                           static_cast<uint32_t *>(const_cast<void *>(d_ws)));
+        return kLaunchers[robot]->validate(env->launch[robot], d_q, n, d_bits, static_cast<hipStream_t>(stream), 7);
     }
 
     int vmv_validate_batch_env(int robot, const vmv_env *env, const float *d_q, size_t n, uint64_t *d_bits, void *stream)
@@ -994,7 +950,7 @@ extern "C"
         if (n == 0) return VMV_OK;
         if (int rc = check_device(env); rc != VMV_OK) return rc;
         if (int rc = ensure_robot(env, robot); rc != VMV_OK) return rc;
-        return kLaunchers[robot]->validate(env->launch[robot], d_q, n, d_bits, static_cast<hipStream_t>(stream), 1, nullptr);
+        return kLaunchers[robot]->validate(env->launch[robot], d_q, n, d_bits, static_cast<hipStream_t>(stream), 1);
     }
 
     int vmv_validate_batch_self(int robot, const float *d_q, size_t n, uint64_t *d_bits, void *stream)
@@ -1002,7 +958,7 @@ extern "C"
         if (!robot_ok(robot)) return VMV_ERR_UNKNOWN_ROBOT;
         if (!d_q || !d_bits) return VMV_ERR_INVALID_ARGUMENT;
         if (n == 0) return VMV_OK;
-        return kLaunchers[robot]->validate(vmv::EnvLaunch{}, d_q, n, d_bits, static_cast<hipStream_t>(stream), 2, nullptr);
+        return kLaunchers[robot]->validate(vmv::EnvLaunch{}, d_q, n, d_bits, static_cast<hipStream_t>(stream), 2);
     }
 
     int vmv_validate_motion_batch(int robot, const vmv_env *env, const float *d_a, const float *d_b, size_t n,

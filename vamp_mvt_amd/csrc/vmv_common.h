@@ -14,17 +14,6 @@ namespace vmv
     constexpr uint32_t kMaxLdsBytes = 160u * 1024u;   // gfx950 LDS per CU / max per workgroup
     constexpr uint32_t kMaxPrimFloats = 12u * 1024u;  // 48 KiB of primitive records
 
-    // Workspace of vmv_validate_batch's two kernels (optional): the environment kernel lists the configurations it leaves
-    // valid, the self-collision kernel runs FK for those only.  uint32 words: [64 counters | 64 sub-lists of `cap`
-    // configuration indices]; sub-list = wave index mod 64, so cap = 64 * ceil(waves / 64).
-    constexpr int kValidateSublists = 64;
-    inline uint32_t validate_ws_cap(size_t n)
-    {
-        const size_t waves = (n + kWave - 1) / kWave;
-        return (uint32_t) (((waves + kValidateSublists - 1) / kValidateSublists) * kWave);
-    }
-    inline size_t validate_ws_bytes(size_t n) { return ((size_t) kValidateSublists * (1u + (size_t) validate_ws_cap(n))) * sizeof(uint32_t); }
-
     // what a launcher needs to know about a finalized environment
     struct EnvLaunch
     {
@@ -37,8 +26,7 @@ namespace vmv
     {
         // stage bit 1 = environment kernel (writes the words), bit 2 = self-collision kernel, bit 4 = attachment kernel
         // (both AND into them; the attachment kernel only runs for environments with an attachment)
-        // ws: nullptr or validate_ws_bytes(n) bytes of device memory (stage 1 fills it, stage 2 walks it)
-        int (*validate)(const EnvLaunch &, const float *d_q, size_t n, uint64_t *d_bits, hipStream_t, int stages, uint32_t *ws);
+        int (*validate)(const EnvLaunch &, const float *d_q, size_t n, uint64_t *d_bits, hipStream_t, int stages);
         int (*validate_motion)(const EnvLaunch &, const float *d_a, const float *d_b, size_t n, uint64_t *d_bits,
                                hipStream_t);
         int (*fk)(const float *d_q, size_t n, float *d_out, hipStream_t);
