@@ -100,6 +100,12 @@ def main():
             print(f"case {case} seed {seed} {robot}: environment rejected ({type(e).__name__}: {e})", flush=True)
             case += 1
             continue
+        # the self-collision kernel's words-per-wave grouping is sized from the batch; small batches would always get 1
+        group = rng.choice(["", "1", "2", "3", "5", "8"])
+        if group:
+            os.environ["VMV_SELF_GROUP"] = str(group)
+        else:
+            os.environ.pop("VMV_SELF_GROUP", None)
         rid = o.robot(robot)
         lo, span = o.bounds(rid)
         mod = getattr(vamp, robot)
