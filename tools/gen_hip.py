@@ -317,15 +317,19 @@ def self_tables(m, N=SELF_TABLE_N):
 
 
 SELF_DEAL_MAX_A = 40  # A-side spheres kept in registers for the re-dealt self-collision form
-ENV_CHUNK = {"panda": 5}   # fine spheres per slab chunk in the environment kernels (default CHUNK); a smaller slab
-ENV_BLOCKS = {"panda": 5, "baxter": 5}  # (baxter: 0.331 -> 0.307 ms per 1M configs at 5)  # ... lets five workgroups (20 waves) share a CU's LDS where the registers allow it
+ENV_CHUNK = {"panda": 5, "ur5": 5}   # fine spheres per slab chunk in the environment kernels (default CHUNK); a smaller slab
+ENV_BLOCKS = {"panda": 5, "ur5": 5, "baxter": 5}  # (baxter: 0.331 -> 0.307 ms per 1M configs at 5)  # ... lets five workgroups (20 waves) share a CU's LDS where the registers allow it
 # workgroups per CU the self kernel is compiled for (512 / blocks VGPRs per lane) and fine spheres per slab chunk of the
 # self-collision kernels.  Panda, measured (blocks x chunk, self kernel ms per 1M configs): 3x8 0.145, 4x8 0.133,
 # 4x7 0.127, 4x6 0.126, 4x5 0.132, 4x4 0.140, 5x5 0.210 - with chunks of 8 the fourth workgroup did not fit the LDS.
 SELF_BLOCKS = {"panda": 4, "ur5": 3, "baxter": 3}  # (baxter: 0.289 -> 0.227 ms at 3; fetch is faster at 2 than at 3)
 SELF_CHUNK = {"panda": 6}
 FUSED_BLOCKS = {"panda": int(os.environ.get("VMV_FUSED_BLOCKS", 4))}
-for _r in ("panda", "ur5", "fetch", "baxter"):  # tuning knobs: VMV_SELF_BLOCKS_<ROBOT>, VMV_SELF_CHUNK_<ROBOT>
+for _r in ("panda", "ur5", "fetch", "baxter"):  # tuning knobs: VMV_{SELF,ENV}_BLOCKS_<ROBOT>, VMV_{SELF,ENV}_CHUNK_<ROBOT>
+    if f"VMV_ENV_BLOCKS_{_r.upper()}" in os.environ:
+        ENV_BLOCKS[_r] = int(os.environ[f"VMV_ENV_BLOCKS_{_r.upper()}"])
+    if f"VMV_ENV_CHUNK_{_r.upper()}" in os.environ:
+        ENV_CHUNK[_r] = int(os.environ[f"VMV_ENV_CHUNK_{_r.upper()}"])
     if f"VMV_SELF_BLOCKS_{_r.upper()}" in os.environ:
         SELF_BLOCKS[_r] = int(os.environ[f"VMV_SELF_BLOCKS_{_r.upper()}"])
     if f"VMV_SELF_CHUNK_{_r.upper()}" in os.environ:
