@@ -37,11 +37,14 @@ def test_bench_line_single_gpu():
     assert {"value", "unit", "cores", "kind", "sample"} <= set(cpu) and cpu["kind"] in ("port", "reference")
     assert 0.55 < d["config"]["valid_fraction"] < 0.70
     assert d["value"] > 1e8  # the north-star floor, by a wide margin
+    two = d["two_streams"]  # informational leg: the same steps on two alternating streams, never `value`
+    assert two["same_words_as_the_timed_run"] is True and two["value"] > 0 and two["unit"] == d["unit"]
+    assert "two_streams" not in _run("--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--no-two-streams")
 
 
 @pytest.mark.gpu
 def test_bench_starts_its_own_ranks_and_reports_weak_and_strong():
     d = _run("--gpus", "2", "--rehearse-on-one-gpu", "--steps", "6", "--warmup", "2")
-    assert REQUIRED <= set(d) and d["n_gpus"] == 2 and "cpu_baseline" not in d
+    assert REQUIRED <= set(d) and d["n_gpus"] == 2 and "cpu_baseline" not in d and "two_streams" not in d
     assert d["strong"]["configs_per_job"] == d["config"]["configs_per_gpu"] and d["strong"]["value"] > 0
     assert abs(d["value"] - 2 * d["config"]["configs_per_gpu"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
