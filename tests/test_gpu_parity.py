@@ -106,7 +106,8 @@ def test_capt_query_copy_changes_no_answer(vamp, oracle, monkeypatch, name, n_po
     """The device walks a derived copy of the affordance arrays (each leaf's points sorted by their distance to the
     leaf's cell, cut per radius bucket: vmv_capt_build.h).  Radii from far below r_min to beyond r_max (the last bucket
     = the whole list), centres in and around the cloud, duplicated points: the answers must be the oracle's, and the
-    same as with VMV_CAPT_NO_PREFIX=1 (every query walks its leaf's whole list, read at finalize)."""
+    same as with VMV_CAPT_NO_PREFIX=1 (every query walks its leaf's whole list, read at finalize) and with
+    VMV_CAPT_NO_DIST_GRID=1 (no "farther than r + r_point from every cloud point" rejection in front of the descent)."""
     import ctypes
     from envs import build_oracle_env, build_product_env
     from vamp_mvt_amd.workloads import POINT_RADIUS, RADII, shell_cloud
@@ -130,11 +131,15 @@ def test_capt_query_copy_changes_no_answer(vamp, oracle, monkeypatch, name, n_po
                                                                       ctypes.c_float(float(s[i, 3])))) for i in range(n)])
     rid, q = uniform_configs(oracle, name, 6000, seed=case_seed("captcopy-cfg", name, n_points) % 100000)
     want_q = oracle.validate_batch(rid, oenv, q, threads=8)
-    for no_prefix in ("0", "1"):
+    for no_prefix, no_grid in (("0", "0"), ("0", "1"), ("1", "0")):
         monkeypatch.setenv("VMV_CAPT_NO_PREFIX", no_prefix)
+        if no_grid == "1":
+            monkeypatch.setenv("VMV_CAPT_NO_DIST_GRID", "1")  # no distance grid in front of the descent
+        else:
+            monkeypatch.delenv("VMV_CAPT_NO_DIST_GRID", raising=False)
         env = build_product_env(spec)
-        assert np.array_equal(env.spheres_in_collision(s), want), no_prefix
-        assert np.array_equal(getattr(vamp, name).validate_batch(q, env), want_q), no_prefix
+        assert np.array_equal(env.spheres_in_collision(s), want), (no_prefix, no_grid)
+        assert np.array_equal(getattr(vamp, name).validate_batch(q, env), want_q), (no_prefix, no_grid)
     if n_points >= 3000:
         _non_degenerate(want, n)
 

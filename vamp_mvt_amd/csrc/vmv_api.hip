@@ -637,7 +637,7 @@ extern "C"
                 if (!(std::fabs(a.aabb_top[k]) <= 1e3f)) prune = false;  // the 1e-4 m margin is sized for metre-scale clouds
             vmv::CaptQueryDev q;
             const int rc = vmv::build_capt_query(c.tests, c.aff_starts, c.aabbs, c.aff_x, c.aff_y, c.aff_z, a.nlog2, n_vectors,
-                                                 a.r_min, a.r_max, a.r_point, prune, q);
+                                                 a.r_min, a.r_max, a.r_point, prune, a.aabb_top, q);
             if (rc != VMV_OK)
             {
                 if (rc == VMV_ERR_CAPACITY) g_last_error = "point cloud too large for the device query copy";
@@ -650,6 +650,10 @@ extern "C"
             c.q_leaves = q.leaves;
             c.q_planes = q.planes;
             c.cut_t0 = q.t0, c.cut_inv_step = q.inv_step;
+            c.q_dist = q.dist;
+            if (q.dist) env->allocations.push_back(q.dist);
+            for (int k = 0; k < 3; ++k) c.dist_dims[k] = q.dist_dims[k], c.dist_origin[k] = q.dist_origin[k];
+            c.dist_inv_cell = q.dist_inv_cell;
             return VMV_OK;
         };
         for (size_t i = 0; i < env->capts.size(); ++i)

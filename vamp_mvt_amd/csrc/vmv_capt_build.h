@@ -249,8 +249,15 @@ namespace vmv
         uint32_t *leaves = nullptr;  // 2^nlog2 * kCaptLeafWords
         float *planes = nullptr;     // blocked copy of `tests` (vmv_device.h: capt_plane_slot)
         float t0 = 0.f, inv_step = 0.f;
+        // distance grid (optional, nullptr = none): for every cell of a uniform grid over the cloud's box a LOWER bound of
+        // the distance from any point of the cell to the nearest cloud point (distance at the cell centre - half a cell
+        // diagonal, rounded down).  A query whose cell's bound exceeds r + r_point + 1e-4 m cannot touch any point of
+        // the cloud, whatever leaf it descends to: it is rejected before the descent (pruning only).
+        float *dist = nullptr;
+        uint32_t dist_dims[3] = {0, 0, 0};
+        float dist_origin[3] = {0, 0, 0}, dist_inv_cell = 0.f;
     };
     int build_capt_query(const float *d_tests, const uint32_t *d_aff_starts, const float *d_aabbs, const float *d_ax,
                          const float *d_ay, const float *d_az, uint32_t nlog2, uint32_t n_vectors, float r_min, float r_max,
-                         float r_point, bool prune, CaptQueryDev &out);
+                         float r_point, bool prune, const float aabb_top[6], CaptQueryDev &out);
 }  // namespace vmv

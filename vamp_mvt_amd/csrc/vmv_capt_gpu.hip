@@ -25,6 +25,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <vector>
@@ -673,11 +674,49 @@ namespace
         const uint32_t l = 31u - (uint32_t) __clz((int) (i + 1u));
         planes[capt_plane_slot(nlog2, l, i)] = tests[i];
     }
+    // one thread per grid cell: distance from the cell centre to the nearest cloud point (the representative point of
+    // every leaf = the first slot of its first vector; padding leaves hold +inf), minus the half diagonal, rounded down
+    __global__ void capt_query_dist_kernel(const uint32_t *__restrict__ starts, const float *__restrict__ ax, const float *__restrict__ ay,
+                                           const float *__restrict__ az, uint32_t leaves, uint32_t d0, uint32_t d1, uint32_t d2,
+                                           float ox, float oy, float oz, float h, float *__restrict__ out)
+    {
+        __shared__ float px[kT], py[kT], pz[kT];
+        const size_t cell = (size_t) blockIdx.x * kT + threadIdx.x;
+        const size_t n_cells = (size_t) d0 * d1 * d2;
+        const uint32_t iz = (uint32_t) (cell % d2), iy = (uint32_t) ((cell / d2) % d1), ix = (uint32_t) (cell / ((size_t) d1 * d2));
+        const float cx = ox + ((float) ix + 0.5f) * h, cy = oy + ((float) iy + 0.5f) * h, cz = oz + ((float) iz + 0.5f) * h;
+        float best = HUGE_VALF;
+        for (uint32_t base = 0; base < leaves; base += kT)
+        {
+            const uint32_t l = base + threadIdx.x;
+            float x = HUGE_VALF, y = HUGE_VALF, z = HUGE_VALF;
+            if (l < leaves && starts[l + 1] > starts[l])
+            {
+                const size_t s = (size_t) starts[l] * 8;
+                x = ax[s], y = ay[s], z = az[s];
+            }
+            __syncthreads();
+            px[threadIdx.x] = x, py[threadIdx.x] = y, pz[threadIdx.x] = z;
+            __syncthreads();
+            const uint32_t m = (leaves - base < (uint32_t) kT) ? leaves - base : (uint32_t) kT;
+            for (uint32_t k = 0; k < m; ++k)
+            {
+                const float dx = px[k] - cx, dy = py[k] - cy, dz = pz[k] - cz;
+                const float d = dx * dx + dy * dy + dz * dz;
+                best = (d < best) ? d : best;  // (inf and NaN never win)
+            }
+        }
+        if (cell >= n_cells) return;
+        // lower bound for any centre the device maps to this cell: cells are taken 1 % larger than they are (fp32 cell
+        // index at the borders), fp32 rounding of the distance itself is covered by the 1e-5
+        const float lb = sqrtf(best) * (1.0f - 1e-6f) - 0.5f * 1.7320508f * h * 1.01f - 1e-5f;
+        out[cell] = (best < HUGE_VALF) ? fmaxf(lb, 0.0f) : HUGE_VALF;
+    }
 }  // namespace
 
 int build_capt_query(const float *d_tests, const uint32_t *d_aff_starts, const float *d_aabbs, const float *d_ax,
                      const float *d_ay, const float *d_az, uint32_t nlog2, uint32_t n_vectors, float r_min, float r_max,
-                     float r_point, bool prune, CaptQueryDev &out)
+                     float r_point, bool prune, const float aabb_top[6], CaptQueryDev &out)
 {
     out = CaptQueryDev{};
     if (nlog2 == 0 || nlog2 > 24 || (size_t) n_vectors * 8 >= (size_t{1} << 31)) return VMV_ERR_CAPACITY;
@@ -723,6 +762,39 @@ int build_capt_query(const float *d_tests, const uint32_t *d_aff_starts, const f
     VMV_C(b_planes.reserve(plane_floats * 4));
     VMV_C(hipMemsetAsync(b_planes.p, 0, plane_floats * 4, s));
     hipLaunchKernelGGL(capt_query_planes_kernel, dim3(nblk(n_tests)), dim3(kT), 0, s, d_tests, nlog2, n_tests, b_planes.as<float>());
+    // distance grid over the cloud's box (queries pass the reference's top-box test first, so their centres lie within
+    // the box grown by their radius; centres outside the grid are simply not rejected)
+    DevBuf b_dist;
+    uint32_t dd[3] = {0, 0, 0};
+    float dorg[3] = {0, 0, 0}, dh = 0.f;
+    if (prune && std::getenv("VMV_CAPT_NO_DIST_GRID") == nullptr)
+    {
+        const double pad = (double) r_max + (double) r_point + 0.05;
+        double ext[3], vol = 1.0;
+        bool ok = true;
+        for (int k = 0; k < 3; ++k)
+        {
+            ext[k] = ((double) aabb_top[3 + k] + pad) - ((double) aabb_top[k] - pad);
+            ok = ok && std::isfinite(ext[k]) && ext[k] > 0.0 && ext[k] < 1e3;
+            vol *= ext[k];
+        }
+        if (ok)
+        {
+            // cells: at most ~1M, and at most 4e10 point-cell pairs for the brute-force build
+            const double max_cells = std::min(1.0e6, 4.0e10 / (double) leaves);
+            dh = (float) std::max(0.03, std::cbrt(vol / max_cells));
+            size_t n_cells = 1;
+            for (int k = 0; k < 3; ++k)
+            {
+                dd[k] = (uint32_t) std::ceil(ext[k] / (double) dh);
+                dorg[k] = (float) ((double) aabb_top[k] - pad);
+                n_cells *= dd[k];
+            }
+            VMV_C(b_dist.reserve(n_cells * 4));
+            hipLaunchKernelGGL(capt_query_dist_kernel, dim3(nblk(n_cells)), dim3(kT), 0, s, d_aff_starts, d_ax, d_ay, d_az, leaves, dd[0],
+                               dd[1], dd[2], dorg[0], dorg[1], dorg[2], dh, b_dist.as<float>());
+        }
+    }
     VMV_C(hipGetLastError());
     VMV_C(hipStreamSynchronize(s));
     auto release = [](DevBuf &b)
@@ -737,6 +809,12 @@ int build_capt_query(const float *d_tests, const uint32_t *d_aff_starts, const f
     out.planes = static_cast<float *>(release(b_planes));
     out.t0 = t0;
     out.inv_step = 1.0f / step;
+    if (b_dist.p)
+    {
+        out.dist = static_cast<float *>(release(b_dist));
+        for (int k = 0; k < 3; ++k) out.dist_dims[k] = dd[k], out.dist_origin[k] = dorg[k];
+        out.dist_inv_cell = 1.0f / dh;
+    }
     return VMV_OK;
 }
 

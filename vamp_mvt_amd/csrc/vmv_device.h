@@ -157,6 +157,11 @@ namespace vmv
         uint32_t n_tests;
         float cut_t0, cut_inv_step;
         uint32_t pad_;
+        const float *q_dist;   // distance grid (nullptr: none): lower bound of the distance to the nearest cloud point per cell
+        uint32_t dist_dims[3];
+        float dist_inv_cell;
+        float dist_origin[3];
+        uint32_t pad2_;
         // the reference's layout (what inspection returns; `tests` also feeds the LDS copy of the top levels)
         const float *tests;          // 2^nlog2 - 1
         const uint32_t *aff_starts;  // 2^nlog2 + 1
@@ -398,12 +403,28 @@ namespace vmv
         inb = inb && (y + r >= t1) && (y - r <= t4);
         inb = inb && (z + r >= t2) && (z - r <= t5);
         if (!wave_any(inb) || VMV_ABLATE_ENV == 6) return false;
+        // distance grid: a centre whose cell is farther from every cloud point than r + r_point (+ 1e-4 m) cannot hit
+        // whatever leaf it descends to (the leaf lists are subsets of the cloud).  The load is issued here and used after
+        // the LDS part of the descent; if no lane is left, the wave skips the rest of the descent, the leaf record and the walk.
+        const gf_cptr dgrid = (gf_cptr) D->capt[ci].q_dist;
+        float dist_lb = 0.0f;
+        if (dgrid != nullptr)
+        {
+            const float inv = D->capt[ci].dist_inv_cell;
+            const float fx = (x - D->capt[ci].dist_origin[0]) * inv, fy = (y - D->capt[ci].dist_origin[1]) * inv,
+                        fz = (z - D->capt[ci].dist_origin[2]) * inv;
+            const uint32_t g0 = D->capt[ci].dist_dims[0], g1 = D->capt[ci].dist_dims[1], g2 = D->capt[ci].dist_dims[2];
+            const bool in_grid = inb && fx >= 0.0f && fy >= 0.0f && fz >= 0.0f && fx < (float) g0 && fy < (float) g1 && fz < (float) g2;
+            const size_t cell = in_grid ? ((size_t) (uint32_t) fx * g1 + (uint32_t) fy) * g2 + (uint32_t) fz : 0;
+            dist_lb = in_grid ? dgrid[cell] : 0.0f;
+        }
 
         // descent through the blocked copy of the planes (capt_plane_slot): three levels per step — one block of 7
         // planes fetched at once (LDS for the leading groups staged there, n_lds floats; one 32-byte read through
         // L1 / L2 below), then three compares on values already in registers.  `path` (one bit per level) is the block
         // number inside the next group and, after the last level, the leaf.
         uint32_t path = 0u, k = 0u, base = 0u;
+        bool checked = false;
         for (uint32_t gs = 0u; gs < nlog2;)
         {
             const uint32_t nl = capt_group_levels(nlog2, gs);
@@ -416,6 +437,12 @@ namespace vmv
             }
             else
             {
+                if (!checked)  // first group outside LDS: the distance bound has had the LDS groups to arrive
+                {
+                    checked = true;
+                    inb = inb && !(dist_lb > (r + r_point) + kCaptCutMargin);
+                    if (!wave_any(inb)) return false;
+                }
                 const g_v4f *b = (const g_v4f *) (bplanes + base + (size_t) path * kCaptPlaneBlock);
                 pa = b[0], pb = b[1];
             }
@@ -440,6 +467,11 @@ namespace vmv
             }
             base = next;
             gs += nl;
+        }
+        if (!checked)
+        {
+            inb = inb && !(dist_lb > (r + r_point) + kCaptCutMargin);
+            if (!wave_any(inb)) return false;
         }
         const uint32_t zi = path;
         if (VMV_ABLATE_ENV == 7) return zi == 0x12345u;
