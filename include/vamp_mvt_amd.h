@@ -16,6 +16,12 @@
  *     is 1 iff configuration/edge i is VALID (collision free).  d_bits must hold ceil(n / 64) words.
  *   - an environment is immutable after vmv_env_finalize() and may then be used from any thread/stream.
  *   - there is no CPU fallback: every compute entry point fails with VMV_ERR_NO_DEVICE without a GPU.
+ *   - non-finite input is DEFINED: a configuration with a NaN or +-inf joint is INVALID (bit 0), an edge with such an
+ *     endpoint is INVALID; nothing is evaluated for it.  (The reference has no rule: its sign-bit predicates read the
+ *     sign of a propagated NaN, vector/interface.hh:257-277 — an artefact of the instruction set.)  vmv_fk_batch /
+ *     vmv_eefk_batch return NaN spheres / frames for such a configuration.
+ *   - bits of the last word at or beyond n are written as 0; the entry points that AND into existing words
+ *     (vmv_validate_batch_self) ignore and clear them.
  */
 #ifndef VAMP_MVT_AMD_H
 #define VAMP_MVT_AMD_H
@@ -187,6 +193,9 @@ int vmv_eefk_batch_host(int robot, const float *q, size_t n, float *out);
 int vmv_validate_batch_host(int robot, const vmv_env *env, const float *q, size_t n, uint64_t *bits);
 int vmv_validate_motion_batch_host(int robot, const vmv_env *env, const float *start, const float *goal, size_t n,
                                    uint64_t *bits);
+/* The host-buffer variants stage through a per-thread device arena that is reused between calls (requests above 64 MiB
+ * are not kept).  Frees the calling thread's arena; optional — the arena is never touched at thread or process exit. */
+int vmv_release_staging(void);
 
 /* ---- multi-GPU: one process per GPU, every unit independent given the read-only environment ------- */
 /* Contiguous shard [*lo, *hi) of an n-unit batch (configurations or edges) for `rank` of `world`: every boundary except

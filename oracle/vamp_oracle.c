@@ -1389,16 +1389,30 @@ int vo_validate(int robot, const vo_env *e, const float *q, int check_bounds)
     return validate_vector(robot, e, q, vector, 0.F, 1, 1);
 }
 
+/* The batch entry points mirror the C ABI's (include/vamp_mvt_amd.h), including its one rule the reference does not
+ * have: a unit with a NaN or +-inf joint is INVALID.  vo_validate / vo_validate_motion above stay the plain restatement:
+ * for such input the reference reads the sign bit of whichever NaN each x86 instruction propagates, an artefact no
+ * caller of the path relies on (no sampler or planner produces non-finite joints). */
+static int all_finite(const float *q, size_t dim)
+{
+    for (size_t j = 0; j < dim; ++j)
+        if (!isfinite(q[j])) return 0;
+    return 1;
+}
+
 void vo_validate_batch(int robot, const vo_env *e, const float *q, size_t n, uint8_t *out)
 {
     const size_t dim = vo_robots[robot].dimension;
-    for (size_t i = 0; i < n; ++i) out[i] = (uint8_t) vo_validate(robot, e, q + i * dim, 0);
+    for (size_t i = 0; i < n; ++i)
+        out[i] = (uint8_t) (all_finite(q + i * dim, dim) && vo_validate(robot, e, q + i * dim, 0));
 }
 
 void vo_validate_motion_batch(int robot, const vo_env *e, const float *a, const float *b, size_t n, uint8_t *out)
 {
     const size_t dim = vo_robots[robot].dimension;
-    for (size_t i = 0; i < n; ++i) out[i] = (uint8_t) vo_validate_motion(robot, e, a + i * dim, b + i * dim);
+    for (size_t i = 0; i < n; ++i)
+        out[i] = (uint8_t) (all_finite(a + i * dim, dim) && all_finite(b + i * dim, dim) &&
+                            vo_validate_motion(robot, e, a + i * dim, b + i * dim));
 }
 
 typedef struct
@@ -1893,7 +1907,8 @@ int vo_validate_batch_avx2(int robot, const vo_env *e, const float *q, size_t n,
         v8f rake[16];
         for (size_t j = 0; j < dim; ++j) rake[j] = _mm256_load_ps(block[j]);
         const unsigned valid = v8_fkcc(robot, e, rake, (1u << cnt) - 1u);
-        for (unsigned l = 0; l < cnt; ++l) out[base + l] = (uint8_t) ((valid >> l) & 1u);
+        for (unsigned l = 0; l < cnt; ++l) /* + the boundary rule for non-finite joints (vo_validate_batch) */
+            out[base + l] = (uint8_t) (((valid >> l) & 1u) && all_finite(q + (base + l) * dim, dim));
     }
     return 0;
 }

@@ -337,6 +337,72 @@ def test_edge_cases(vamp, oracle):
         p.validate_batch(q[:, :6], env)
 
 
+@pytest.mark.parametrize("name", ROBOTS)
+@pytest.mark.parametrize("kind", ["empty", "shell64", "capt"])
+def test_non_finite_joints_are_invalid_by_rule(vamp, oracle, name, kind):
+    """include/vamp_mvt_amd.h: a configuration with a NaN / +-inf joint is INVALID, an edge with such an endpoint too; the
+    finite units of the same waves / rakes keep the reference's answers (the oracle's batch entry points carry the same
+    rule; VERDICT r2 item 6 — before it a third of such inputs differed, profiles/r02_nonfinite_inputs_survey.txt)."""
+    env, oenv = make_env(kind, oracle, name)
+    mod = getattr(vamp, name)
+    n = 3000
+    rid, q, want_clean = mixed_configs(oracle, name, oenv, n, case_seed(name, kind, "nonfinite"))
+    rng = np.random.default_rng(case_seed(name, kind, "nonfinite-where") % 100000)
+    specials = np.array([np.nan, -np.nan, np.inf, -np.inf], np.float32)
+    dirty = q.copy()
+    rows = rng.choice(n, n // 3, replace=False)
+    dirty[rows, rng.integers(0, q.shape[1], rows.size)] = specials[rng.integers(0, 4, rows.size)]
+    dirty[rows[:50]] = np.float32(np.nan)  # every joint
+    got = mod.validate_batch(dirty, env)
+    poisoned = np.zeros(n, bool)
+    poisoned[rows] = True
+    assert not got[poisoned].any()
+    assert np.array_equal(got[~poisoned], want_clean[~poisoned]) and want_clean[~poisoned].any()
+    assert np.array_equal(got, oracle.validate_batch(rid, oenv, dirty))
+    assert mod.validate(dirty[rows[0]], env) is False
+    # edges: start, goal or both
+    m = 1200
+    rid, a, b, want_e = mixed_edges(oracle, name, oenv, m, case_seed(name, kind, "nonfinite-edges"), zero_every=9)
+    da, db = a.copy(), b.copy()
+    e_rows = rng.choice(m, m // 3, replace=False)
+    for i, r in enumerate(e_rows):
+        tgt = (da, db, da)[i % 3]
+        tgt[r, rng.integers(0, a.shape[1])] = specials[i % 4]
+        if i % 3 == 2:
+            db[r, rng.integers(0, a.shape[1])] = specials[(i + 1) % 4]
+    got_e = mod.validate_motion_batch(da, db, env)
+    bad_e = np.zeros(m, bool)
+    bad_e[e_rows] = True
+    assert not got_e[bad_e].any()
+    assert np.array_equal(got_e[~bad_e], want_e[~bad_e]) and want_e[~bad_e].any()
+    assert np.array_equal(got_e, oracle.validate_motion_batch(rid, oenv, da, db))
+
+
+@pytest.mark.parametrize("name", ROBOTS)
+@pytest.mark.parametrize("n", [1, 37, 64, 100, 4097])
+def test_self_collision_stage_alone_ignores_bits_beyond_n(vamp, oracle, name, n):
+    """vmv_validate_batch_self is an entry point of its own and ANDs into the caller's words.  With all-ones
+    words and n % 64 != 0 it must neither read configurations past the end of d_q nor leave bits >= n set: the result is
+    the self-collision answer (= validity in the empty environment) of the n configurations, tail bits 0."""
+    import ctypes
+    torch = pytest.importorskip("torch")
+    rid, q = uniform_configs(oracle, name, n, seed=n)
+    tq = torch.from_numpy(q).cuda()  # exactly n rows: anything read beyond them is outside the allocation's payload
+    words = torch.full(((n + 63) // 64,), -1, dtype=torch.int64, device="cuda")
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    rc = vamp.lib.vmv_validate_batch_self(rid_of(vamp, name), ctypes.c_void_p(tq.data_ptr()), n,
+                                          ctypes.c_void_p(words.data_ptr()), stream)
+    assert rc == 0
+    torch.cuda.synchronize()
+    bits = np.unpackbits(words.cpu().numpy().view(np.uint8), bitorder="little")
+    assert not bits[n:].any()
+    assert np.array_equal(bits[:n].astype(bool), oracle.validate_batch(rid, oracle.env(), q))
+
+
+def rid_of(vamp, name):
+    return vamp.lib.vmv_robot_id(name.encode())
+
+
 def test_large_primitive_lists_and_capacity(vamp, oracle):
     env, oenv = make_env("many", oracle)
     rid, q = uniform_configs(oracle, "panda", 8000, seed=4)
@@ -455,29 +521,41 @@ print("fused ok")
     assert r.returncode == 0 and "fused ok" in r.stdout, r.stderr[-2000:]
 
 
-@pytest.mark.parametrize("cfg", ["config3", "config4", "config5"])
+@pytest.mark.parametrize("cfg", ["config3", "config4", "config5", "config4_uniform_starts"])
 def test_full_size_baseline_configs(vamp, oracle, cfg):
     """BASELINE configs 3, 4, 5 at their full sizes (1M Fetch configurations vs a 10k-point CAPT cloud; 1M UR5 edges vs
     64 primitives; 262,144 Baxter edges vs 32 primitives + a 10k-point CAPT cloud): size-independent properties and
-    sampled oracle parity, on the generators of tools/bench_configs.py."""
+    sampled oracle parity, on the generators of tools/bench_configs.py.  Edge batches are roadmap-shaped (SURVEY.md
+    §8d-4/5; planning/prm.hh:109-145, fcit.hh:137-260 only ever validate edges between VALID samples): config 4 joins
+    valid Halton samples to valid neighbours at U[0.2, 1.5] rad, config 5 is the 8-nearest-neighbour graph over valid
+    Halton samples; `config4_uniform_starts` keeps the generator of rounds 1-2 (uniform, mostly invalid starts)."""
     torch = pytest.importorskip("torch")
     from envs import build_oracle_env, build_product_env, spec_for
-    from vamp_mvt_amd.workloads import shell_spec
+    from vamp_mvt_amd.workloads import knn_shaped_edges, prm_shaped_edges, shell_spec
 
+    base = cfg.split("_")[0]
     name, n, edges = {"config3": ("fetch", 1 << 20, False), "config4": ("ur5", 1 << 20, True),
-                      "config5": ("baxter", 1 << 18, True)}[cfg]
-    spec = shell_spec(0) if cfg == "config4" else spec_for(cfg, name)
+                      "config5": ("baxter", 1 << 18, True)}[base]
+    spec = shell_spec(0) if base == "config4" else spec_for(base, name)
     env, oenv = build_product_env(spec), build_oracle_env(oracle, spec)
     mod = getattr(vamp, name)
     rid = oracle.robot(name)
     lo, span = oracle.bounds(rid)
     rng = np.random.default_rng(case_seed(cfg) % 100000)
-    a = (lo + span * rng.random((n, len(lo)), dtype=np.float32)).astype(np.float32)
-    if edges:  # uniform starts, random directions, lengths as in tools/bench_configs.py
-        d = rng.normal(size=a.shape).astype(np.float32)
-        d /= np.linalg.norm(d, axis=1, keepdims=True)
-        length = rng.uniform(*((0.2, 1.5) if cfg == "config4" else (0.1, 0.6)), (n, 1)).astype(np.float32)
-        b = (a + d * length).astype(np.float32)
+    if cfg == "config4":
+        ta, tb = prm_shaped_edges(mod, env, n, 0.2, 1.5, seed=case_seed(cfg) % 100000)
+        a, b = ta.cpu().numpy(), tb.cpu().numpy()
+    elif cfg == "config5":
+        ta, tb = knn_shaped_edges(mod, env, n, 8)
+        a, b = ta.cpu().numpy(), tb.cpu().numpy()
+    else:
+        a = (lo + span * rng.random((n, len(lo)), dtype=np.float32)).astype(np.float32)
+        if edges:  # uniform starts, random directions
+            d = rng.normal(size=a.shape).astype(np.float32)
+            d /= np.linalg.norm(d, axis=1, keepdims=True)
+            b = (a + d * rng.uniform(0.2, 1.5, (n, 1)).astype(np.float32)).astype(np.float32)
+    if cfg in ("config4", "config5"):  # roadmap-shaped: both endpoints valid, so edges are walked, not dropped at rake 0
+        assert mod.validate_batch(ta, env).all() and mod.validate_batch(tb, env).all()
     ta = torch.from_numpy(a).cuda()
     tb = torch.from_numpy(b).cuda() if edges else None
 
@@ -486,6 +564,8 @@ def test_full_size_baseline_configs(vamp, oracle, cfg):
 
     v = run(ta, tb)
     assert v.shape == (n,) and 0.005 * n < v.sum() < 0.995 * n
+    if cfg in ("config4", "config5"):
+        assert v.mean() > 0.05  # a real share of edges is walked to its last rake
     # permutation equivariance and batch-split invariance: a unit's answer does not depend on its position / wave / rake
     perm = torch.from_numpy(np.random.default_rng(1).permutation(n)).cuda()
     assert np.array_equal(run(ta[perm].contiguous(), tb[perm].contiguous() if edges else None), v[perm.cpu().numpy()])
@@ -499,7 +579,7 @@ def test_full_size_baseline_configs(vamp, oracle, cfg):
         goal_ok = mod.validate_batch(tb, env).cpu().numpy()
         assert not np.any(v & ~goal_ok)
     # sampled oracle parity at full size
-    m = 40000 if cfg == "config3" else (20000 if cfg == "config4" else 4000)
+    m = 40000 if cfg == "config3" else (20000 if base == "config4" else 4000)
     idx = np.random.default_rng(2).choice(n, m, replace=False)
     want = oracle.validate_motion_batch(rid, oenv, a[idx], b[idx], threads=8) if edges else \
         oracle.validate_batch(rid, oenv, a[idx], threads=8)

@@ -138,3 +138,24 @@ def test_avx2_rake_of_eight_build_equals_the_scalar_port(oracle, name):
     capt = build_oracle_env(oracle, spec_for("capt", name))
     with pytest.raises(ValueError):
         oracle.validate_batch_avx2(rid, capt, q[:64])
+
+
+def test_batch_entry_points_call_non_finite_units_invalid(oracle):
+    """The boundary rule of include/vamp_mvt_amd.h, mirrored by the oracle's BATCH entry points (vo_validate_batch,
+    vo_validate_motion_batch, the AVX2 build): a NaN / +-inf joint makes the unit invalid.  vo_validate itself stays the
+    plain restatement of the reference (whose answer for such input is an artefact of NaN sign propagation)."""
+    rid = oracle.robot("panda")
+    env = oracle.env()
+    q = np.tile(np.asarray(CAGE_START, np.float32), (16, 1))
+    assert oracle.validate_batch(rid, env, q).all()
+    for i, s in enumerate([np.nan, -np.nan, np.inf, -np.inf]):
+        q[2 * i + 1, (3 * i) % 7] = s
+    want = np.ones(16, bool)
+    want[[1, 3, 5, 7]] = False
+    assert np.array_equal(oracle.validate_batch(rid, env, q), want)
+    assert np.array_equal(oracle.validate_batch(rid, env, q, threads=4), want)
+    clean = np.tile(np.asarray(CAGE_START, np.float32), (16, 1))
+    assert np.array_equal(oracle.validate_motion_batch(rid, env, q, clean), want)
+    assert np.array_equal(oracle.validate_motion_batch(rid, env, clean, q), want)
+    if hasattr(oracle, "validate_batch_avx2") and oracle.has_avx2():
+        assert np.array_equal(oracle.validate_batch_avx2(rid, env, q), want)

@@ -105,6 +105,28 @@ def test_two_rank_sharded_edge_validation(n):
     assert out[0] and out[1]
 
 
+def test_empty_shard_enters_the_collective_on_the_ranks_device(monkeypatch):
+    """a rank whose shard is empty (n = 40 or 100 units on 8 GPUs) used to build CPU buffers and hand them to
+    the RCCL all-gather.  Every tensor given to the collective must live on the device the caller names — here the
+    `meta` device, which no default could produce — on ranks with and without a shard."""
+    seen = []
+
+    def fake_all_gather(out, buf):
+        seen.append((out.device.type, buf.device.type, out.numel(), buf.numel()))
+
+    monkeypatch.setattr(dist, "all_gather_into_tensor", fake_all_gather)
+    for n, world in ((40, 2), (100, 8), (1000, 8)):
+        for rank in range(world):
+            lo, hi = shard_range(n, rank, world)
+            words = validate_sharded(n, lambda a, b: torch.zeros((b - a + 63) // 64, dtype=torch.int64, device="meta"),
+                                     rank, world, device="meta")
+            per = ((n + 63) // 64 + world - 1) // world
+            assert seen[-1] == ("meta", "meta", per * world, per), (n, world, rank, lo, hi)
+            assert words.device.type == "meta" and words.numel() == (n + 63) // 64
+    with pytest.raises(ValueError):  # a local_fn that answers on another device than the collective's is refused
+        validate_sharded(1000, lambda a, b: torch.zeros((b - a + 63) // 64, dtype=torch.int64), 0, 2, device="meta")
+
+
 def test_shard_ranges_are_wave_aligned_and_match_the_c_abi(vamp):
     for n in (1, 63, 64, 65, 1 << 20, 999_999):
         for world in (1, 2, 4, 8):

@@ -112,6 +112,7 @@ def _load():
         "vmv_spheres_in_collision_batch_host": (I, [V, c_float_p, S, ctypes.POINTER(ctypes.c_uint8)]),
         "vmv_validate_batch_host": (I, [I, V, c_float_p, S, c_u64_p]),
         "vmv_validate_motion_batch_host": (I, [I, V, c_float_p, c_float_p, S, c_u64_p]),
+        "vmv_release_staging": (I, []),
         "vmv_halton_configs": (I, [I, ctypes.c_uint64, V, S, V]),
         "vmv_time_validate_batch": (I, [I, V, V, S, V, I, V, c_float_p]),
         "vmv_fill_uniform_configs": (I, [I, V, S, ctypes.c_uint64, V]),

@@ -20,6 +20,7 @@ simplifiers are out of this build's scope): every shortcut is a `
 the GPU.  `xorshift()` raises, as the reference's does where SIMDxorshift is unavailable (robot_helper.hh:406-409)."""
 from __future__ import annotations
 
+import logging
 import math
 import time
 from dataclasses import dataclass, field
@@ -366,66 +367,77 @@ def install(robot):
     robot.roadmap = lambda start, goal, environment, settings, rng: roadmap(start, goal, environment, settings, rng)[0]
 
 
+# ------------------------------------------------------------------- module-level helpers (contract: src/vamp/__init__.py)
+_log = logging.getLogger("vamp_mvt_amd")
+
+
+def _planner_settings(robot_module, robot_name, planner_name):
+    """default settings object of a planner (the reference's per-planner defaults, src/vamp/__init__.py:76-95)"""
+    makers = {
+        "rrtc": lambda: RRTCSettings(range=ROBOT_RRT_RANGES.get(robot_name, RRTCSettings.range)),
+        "prm": lambda: PRMSettings(PRMNeighborParams(robot_module.dimension(), robot_module.space_measure())),
+        "fcit": lambda: FCITSettings(FCITNeighborParams(robot_module.dimension(), robot_module.space_measure())),
+    }
+    if planner_name not in makers:
+        raise NotImplementedError(f"no automatic settings for planner '{planner_name}' in this build")
+    settings = makers[planner_name]()
+    settings.max_iterations = settings.max_samples = DEFAULT_ITERATIONS
+    return settings
+
+
+def _route_kwarg(key, plan_settings, simp_settings):
+    """Where a keyword of configure_robot_and_planner_with_kwargs lands: yields (owner, attribute, label).  The rules
+    are the reference's (src/vamp/__init__.py:100-134): a planner attribute by its own name; a simplifier attribute
+    behind the marker `simplification_`; an attribute of one simplifier routine behind `<routine>_` (markers are
+    matched anywhere in the key and removed from it)."""
+    yield plan_settings, key, "planner"
+    if "simplification_" in key:
+        yield simp_settings, key.replace("simplification_", ""), "simplifier"
+    for routine in ("reduce", "shortcut", "bspline", "perturb"):
+        if routine in key:
+            yield getattr(simp_settings, routine), key.replace(routine + "_", ""), f"simplifier.{routine}"
+
+
 def configure_robot_and_planner_with_kwargs(robots, robot_name: str, planner_name: str, **kwargs):
-    """src/vamp/__init__.py:69-139"""
+    """-> (robot module, planner function, planner settings, simplifier settings); same defaults, keyword routing and
+    errors as the reference's function of this name (src/vamp/__init__.py:69-139)."""
     robot_module = robots[robot_name]
-    planner_func = getattr(robot_module, planner_name, None)
-    if planner_func is None:
+    if not hasattr(robot_module, planner_name):
         raise ValueError(f"Robot {robot_name} does not support planner {planner_name}!")
-    if planner_name == "rrtc":
-        plan_settings = RRTCSettings()
-        if robot_name in ROBOT_RRT_RANGES:
-            plan_settings.range = ROBOT_RRT_RANGES[robot_name]
-    elif planner_name == "prm":
-        plan_settings = PRMSettings(PRMNeighborParams(robot_module.dimension(), robot_module.space_measure()))
-    elif planner_name == "fcit":
-        plan_settings = FCITSettings(FCITNeighborParams(robot_module.dimension(), robot_module.space_measure()))
-    else:
-        raise NotImplementedError(f"Automatic setup for planner {planner_name} is not implemented yet!")
-    plan_settings.max_iterations = DEFAULT_ITERATIONS
-    plan_settings.max_samples = DEFAULT_ITERATIONS
-    for k, v in kwargs.items():
-        if hasattr(plan_settings, k):
-            print(f"Setting planner - {k}: {v}")
-            setattr(plan_settings, k, v)
+    plan_settings = _planner_settings(robot_module, robot_name, planner_name)
     simp_settings = SimplifySettings()
-    for k, v in kwargs.items():
-        if "simplification_" in k:
-            sk = k.replace("simplification_", "")
-            if hasattr(simp_settings, sk):
-                print(f"Setting simplification - {sk}: {v}")
-                if sk == "operations":
-                    v = [getattr(SimplifyRoutine, r) for r in v]
-                setattr(simp_settings, sk, v)
-        for sub in ("reduce", "shortcut", "bspline", "perturb"):
-            if sub not in k:
+    for key, value in kwargs.items():
+        for owner, attribute, label in _route_kwarg(key, plan_settings, simp_settings):
+            if not hasattr(owner, attribute):
                 continue
-            sk = k.replace(f"{sub}_", "")
-            sub_setting = getattr(simp_settings, sub)
-            if hasattr(sub_setting, sk):
-                print(f"Setting simplification - {sub} - {sk}: {v}")
-                setattr(sub_setting, sk, v)
-    return robot_module, planner_func, plan_settings, simp_settings
+            if owner is simp_settings and attribute == "operations":  # routine names -> SimplifyRoutine members
+                value = [getattr(SimplifyRoutine, name) for name in value]
+            _log.info("%s.%s = %r", label, attribute, value)
+            setattr(owner, attribute, value)
+    return robot_module, getattr(robot_module, planner_name), plan_settings, simp_settings
 
 
 def results_to_dict(planning_result, simplification_result=None):
-    """src/vamp/__init__.py:188-228"""
+    """One flat record per solved problem, with the column names of the reference's function of this name
+    (src/vamp/__init__.py:188-228) so that its evaluation scripts' DataFrames keep their columns."""
     try:
-        import pandas as pd
-    except ImportError:
-        raise RuntimeError("pandas is not installed!")
-    data = {"planning_time": pd.Timedelta(nanoseconds=planning_result.nanoseconds),
-            "planning_iterations": planning_result.iterations, "solved": bool(planning_result.path),
-            "planning_graph_size": sum(planning_result.size), "initial_path_vertices": len(planning_result.path),
-            "initial_path_cost": planning_result.path.cost()}
-    if simplification_result:
-        simp = {"simplification_time": pd.Timedelta(nanoseconds=simplification_result.nanoseconds),
-                "simplified_path_vertices": len(simplification_result.path),
-                "simplified_path_cost": simplification_result.path.cost()}
-    else:
-        simp = {"simplification_time": pd.Timedelta(nanoseconds=0),
-                "simplified_path_vertices": data["initial_path_vertices"],
-                "simplified_path_cost": data["initial_path_cost"]}
-    data.update(simp)
-    data.update({"total_time": data["planning_time"] + data["simplification_time"]})
-    return data
+        from pandas import Timedelta
+    except ImportError as exc:
+        raise RuntimeError("pandas is not installed!") from exc
+    plan_path = planning_result.path
+    final = simplification_result if simplification_result else None
+    final_path = final.path if final is not None else plan_path
+    t_plan = Timedelta(nanoseconds=planning_result.nanoseconds)
+    t_simp = Timedelta(nanoseconds=final.nanoseconds if final is not None else 0)
+    return {
+        "planning_time": t_plan,
+        "planning_iterations": planning_result.iterations,
+        "solved": len(plan_path) > 0,
+        "planning_graph_size": sum(planning_result.size),
+        "initial_path_vertices": len(plan_path),
+        "initial_path_cost": plan_path.cost(),
+        "simplification_time": t_simp,
+        "simplified_path_vertices": len(final_path),
+        "simplified_path_cost": final_path.cost(),
+        "total_time": t_plan + t_simp,
+    }

@@ -634,7 +634,7 @@ extern "C"
             bool prune = true;
             if (const char *e = std::getenv("VMV_CAPT_NO_PREFIX")) prune = e[0] != '1';  // measurement / test aid
             for (int k = 0; k < 6; ++k)
-                if (!(std::fabs(a.aabb_top[k]) <= 1e3f)) prune = false;  // the 1e-4 m margin is sized for metre-scale clouds
+                if (!(std::fabs(a.aabb_top[k]) <= 1e2f)) prune = false;  // the 1e-4 m margin is 13 fp32 ulps at 100 m; beyond: walk everything
             vmv::CaptQueryDev q;
             const int rc = vmv::build_capt_query(c.tests, c.aff_starts, c.aabbs, c.aff_x, c.aff_y, c.aff_z, a.nlog2, n_vectors,
                                                  a.r_min, a.r_max, a.r_point, prune, a.aabb_top, q);
@@ -1097,25 +1097,27 @@ extern "C"
     // small calls (one configuration, a handful of edges) do not pay three hipMalloc / hipFree pairs each.
     namespace
     {
+        // Device staging of the *_host entry points, per thread.  Never freed from a destructor: a thread_local of the
+        // main thread is destroyed during static destruction, possibly after the HIP runtime is gone (the memory goes
+        // back with the process).  Long-lived callers release it with vmv_release_staging(); a request above
+        // kStagingKeepBytes is not kept beyond its call, so one huge batch does not pin its memory for the thread's life.
+        constexpr size_t kStagingKeepBytes = size_t{64} << 20;
         struct StagingArena
         {
             void *base = nullptr;
             size_t capacity = 0;
             int device = -1;
-            ~StagingArena()
+            void release()
             {
-                if (base) (void) hipFree(base);  // at thread exit (a no-op error if the runtime is already gone)
+                if (base) (void) hipFree(base);
+                base = nullptr;
+                capacity = 0;
             }
             void *get(size_t bytes)
             {
                 int dev = -1;
                 if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-                if (base && (dev != device || bytes > capacity))
-                {
-                    (void) hipFree(base);
-                    base = nullptr;
-                    capacity = 0;
-                }
+                if (base && (dev != device || bytes > capacity)) release();
                 if (!base)
                 {
                     const size_t want = std::max<size_t>(bytes, 1u << 16);
@@ -1128,6 +1130,10 @@ extern "C"
                     device = dev;
                 }
                 return base;
+            }
+            void trim()
+            {
+                if (capacity > kStagingKeepBytes) release();
             }
         };
         thread_local StagingArena g_staging;
@@ -1152,7 +1158,13 @@ extern "C"
         rc = b ? vmv_validate_motion_batch(robot, env, da, db, n, dbits, nullptr) :
                  vmv_validate_batch(robot, env, da, n, dbits, nullptr);
         if (rc == VMV_OK && hipMemcpy(bits, dbits, wb, hipMemcpyDeviceToHost) != hipSuccess) rc = VMV_ERR_HIP;
+        g_staging.trim();
         return rc;
+    }
+    int vmv_release_staging(void)
+    {
+        g_staging.release();
+        return VMV_OK;
     }
     int vmv_validate_batch_host(int robot, const vmv_env *env, const float *q, size_t n, uint64_t *bits)
     {

@@ -235,7 +235,7 @@ namespace vmv
     //    T_b = t0 + b * step (the last bucket = the whole list).  A query of radius r takes the first bucket with
     //    T_b >= r + r_point + 1e-4 m and tests those vectors with the reference's predicate; every point it skips is
     //    farther than r + r_point by more than 1e-4 m, five orders of magnitude above fp32 rounding at metre scale
-    //    (`prune` = false — VMV_CAPT_NO_PREFIX=1, coordinates beyond +-1e3 m, non-finite radii — keeps the order and
+    //    (`prune` = false — VMV_CAPT_NO_PREFIX=1, coordinates beyond +-1e2 m, non-finite radii — keeps the order and
     //    makes every bucket the whole list);
     //  * leaves: one 128-byte record per leaf = [box lo xyz, hi xyz | first vector | vector count | 32 x uint16 bucket
     //    counts (0xffff = whole list) | pad]: one cache line answers the leaf test and says what to walk;

@@ -610,7 +610,10 @@ namespace
                 d2 += d * d;
             }
             float key = (float) sqrt(d2);
-            if (!(key >= 0.f)) key = 0.f;                                         // NaN input: always tested
+            // padding (+inf) and any other non-finite point sorts LAST (inf - inf above is NaN, which fmax drops: the key
+            // would be 0 and the pads would lead the leaf's list); such a point never satisfies the query's `<=`
+            if (!isfinite(p[0]) || !isfinite(p[1]) || !isfinite(p[2])) key = HUGE_VALF;
+            if (!(key >= 0.f)) key = 0.f;                                         // (NaN distance: always tested)
             if (key > 0.f && key < HUGE_VALF && (double) key * (double) key > d2)  // keep it a lower bound
                 key = __uint_as_float(__float_as_uint(key) - 1u);
             keys[s] = ((unsigned long long) leaf << 32) | (unsigned long long) __float_as_uint(key);

@@ -21,33 +21,43 @@ def shard_range(n: int, rank: int, world: int):
     return lo, hi
 
 
-def gather_bits(local_words, n: int, world: int):
-    """local_words: int64 tensor holding this rank's packed validity words (shard_range order).
-    Returns the int64 words of the whole batch on every rank (all_gather over the default process group)."""
+def gather_bits(local_words, n: int, world: int, device=None):
+    """local_words: int64 tensor holding this rank's packed validity words (shard_range order; empty for a rank whose
+    shard is empty).  Returns the int64 words of the whole batch on every rank (all_gather over the default process
+    group).  `device`: where the collective's buffers live — it must be the SAME kind of device on every rank (the GPU
+    of the rank under RCCL), also on a rank with nothing to contribute; default: the device of `local_words`."""
     import torch
     import torch.distributed as dist
 
+    device = local_words.device if device is None else torch.device(device)
     words = (n + 63) // 64
     per = (words + world - 1) // world
-    buf = torch.zeros(per, dtype=torch.int64, device=local_words.device)
-    buf[: local_words.numel()] = local_words
+    buf = torch.zeros(per, dtype=torch.int64, device=device)
+    buf[: local_words.numel()] = local_words.to(device)
     if world == 1:
         return buf[:words]
-    out = torch.empty(per * world, dtype=torch.int64, device=local_words.device)
+    out = torch.empty(per * world, dtype=torch.int64, device=device)
     dist.all_gather_into_tensor(out, buf)
     return out[:words]
 
 
-def validate_sharded(n: int, local_fn, rank: int, world: int):
+def validate_sharded(n: int, local_fn, rank: int, world: int, device=None):
     """The whole multi-GPU control flow of the path: this rank validates units [lo, hi) of an n-unit batch with
     `local_fn(lo, hi) -> int64 tensor of ceil((hi - lo) / 64) packed validity words` and every rank gets the words of
-    the whole batch back (one all-gather, the path's only exchange step)."""
+    the whole batch back (one all-gather, the path's only exchange step).  A batch smaller than 64 x world units leaves
+    the last ranks without a shard (100 edges on 8 GPUs: ranks 2..7): they launch nothing and still enter the
+    collective, with buffers on `device` (their GPU) like everyone else."""
     import torch
 
     lo, hi = shard_range(n, rank, world)
-    local = local_fn(lo, hi) if hi > lo else torch.zeros(0, dtype=torch.int64)
+    if hi > lo:
+        local = local_fn(lo, hi)
+        if device is not None and local.device != torch.device(device):
+            raise ValueError(f"local_fn returned words on {local.device}, the collective runs on {torch.device(device)}")
+    else:
+        local = torch.zeros(0, dtype=torch.int64, device=device)
     assert local.numel() == (hi - lo + 63) // 64
-    return gather_bits(local, n, world)
+    return gather_bits(local, n, world, device=device)
 
 
 def validate_batch_sharded(robot, configurations, environment, goals=None, rank=None, world=None):
@@ -77,7 +87,7 @@ def validate_batch_sharded(robot, configurations, environment, goals=None, rank=
                                    goals=None if goals is None else shard(goals, lo, hi))
         return bits
 
-    return validate_sharded(n, local_fn, rank, world)
+    return validate_sharded(n, local_fn, rank, world, device=dev)
 
 
 def respawn_one_rank_per_gpu(n_gpus: int, script: str, argv):

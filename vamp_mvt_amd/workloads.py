@@ -89,3 +89,84 @@ def environment_from_spec(spec):
         else:
             e.add_capt_pointcloud(*p)
     return e
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Roadmap-shaped edge batches (BASELINE configs 4 and 5).  The reference's planners only ever ask
+# about edges between VALID samples: PRM connects a new valid sample to its nearest valid neighbours
+# (planning/prm.hh:109-145), FCIT* validates edges of the graph over the valid samples (planning/fcit.hh:137-260).
+# These generators build such batches on the device with the product's own kernels (Halton samples from
+# vmv_halton_configs, validity from vmv_validate_batch); they are workload SETUP and run outside every timed region.
+# torch is plumbing here (device arrays, RNG, top-k).
+# ------------------------------------------------------------------------------------------------------------------
+def valid_halton_samples(mod, env, want, max_draw=1_000_000, chunk=1 << 18):
+    """-> torch float32 CUDA [<= want][dim]: the first `want` VALID samples of the reference's Halton sequence
+    (vamp.<robot>.halton(), generated on the device), in sequence order."""
+    import torch
+
+    kept, have, skip = [], 0, 0
+    while have < want and skip < max_draw:
+        n = min(chunk, max_draw - skip)
+        q = mod.halton_device(n, skip)
+        ok = mod.validate_batch(q, env)
+        q = q[ok]
+        kept.append(q)
+        have += q.shape[0]
+        skip += n
+    out = torch.cat(kept)[:want] if kept else None
+    if out is None or out.shape[0] == 0:
+        raise RuntimeError("no valid Halton sample in this environment")
+    return out.contiguous()
+
+
+def prm_shaped_edges(mod, env, n, dmin, dmax, seed, max_rounds=64):
+    """PRM-roadmap shaped batch (config 4): every edge joins a valid Halton sample to a VALID neighbour configuration at
+    distance U[dmin, dmax] rad in a uniform random direction (rejection sampling on the neighbour's validity; SURVEY.md
+    §8d-4: "valid Halton samples paired with a neighbour at distance U[0.2, 1.5]").  -> (start, goal) CUDA [n][dim]."""
+    import torch
+
+    samples = valid_halton_samples(mod, env, n)
+    dev = samples.device
+    start = samples[torch.arange(n, device=dev) % samples.shape[0]].contiguous()  # sample i serves edges i, i + V, ...
+    goal = torch.empty_like(start)
+    todo = torch.arange(n, device=dev)
+    g = torch.Generator(device=dev).manual_seed(seed)
+    for _ in range(max_rounds):
+        if todo.numel() == 0:
+            break
+        d = torch.randn((todo.numel(), start.shape[1]), generator=g, device=dev)
+        d = d / d.norm(dim=1, keepdim=True)
+        length = dmin + (dmax - dmin) * torch.rand((todo.numel(), 1), generator=g, device=dev)
+        cand = (start[todo] + d * length).contiguous()
+        ok = mod.validate_batch(cand, env)
+        goal[todo[ok]] = cand[ok]
+        todo = todo[~ok]
+    if todo.numel():  # a start boxed in on all sides: give its edge to a start that found neighbours
+        done = torch.ones(n, dtype=torch.bool, device=dev)
+        done[todo] = False
+        src = torch.nonzero(done).flatten()
+        if src.numel() == 0:
+            raise RuntimeError("no valid neighbour found for any sample")
+        pick = src[torch.arange(todo.numel(), device=dev) % src.numel()]
+        start[todo], goal[todo] = start[pick], goal[pick]
+    return start.contiguous(), goal.contiguous()
+
+
+def knn_shaped_edges(mod, env, n, k, seed=0, block=4096):
+    """FCIT*-shaped batch (config 5): the n / k first valid Halton samples, each joined to its k nearest valid samples
+    (L2 in joint space, as the reference's distance).  -> (start, goal) CUDA [n][dim]; n must be a multiple of k."""
+    import torch
+
+    v = n // k
+    samples = valid_halton_samples(mod, env, v)
+    v = samples.shape[0]
+    nbr = []
+    for lo in range(0, v, block):
+        dist = torch.cdist(samples[lo:lo + block], samples)
+        dist[torch.arange(dist.shape[0]), torch.arange(lo, lo + dist.shape[0])] = float("inf")  # not itself
+        nbr.append(dist.topk(min(k, v - 1), largest=False).indices)
+    nbr = torch.cat(nbr)
+    start = samples[:, None, :].expand(-1, nbr.shape[1], -1).reshape(-1, samples.shape[1])
+    goal = samples[nbr.reshape(-1)]
+    reps = (n + start.shape[0] - 1) // start.shape[0]  # fewer valid samples than asked for: repeat the batch
+    return start.repeat(reps, 1)[:n].contiguous(), goal.repeat(reps, 1)[:n].contiguous()
