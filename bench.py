@@ -130,6 +130,7 @@ def main():
     ap.add_argument("--configs", type=int, default=CONFIGS_PER_GPU, help="configurations per GPU per step (weak) and "
                     "per job per step (strong)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-shard-probe", action="store_true", help="skip the timing of the N = 2, 4, 8 shard sizes on this GPU")
     ap.add_argument("--no-two-streams", action="store_true",
                     help="skip the informational two-stream leg (profiling runs: its overlapping launches would mix into the per-kernel averages)")
     ap.add_argument("--cpu-sample", type=int, default=1 << 21)
@@ -274,6 +275,20 @@ def main():
     else:
         elapsed_s, strong_valid = elapsed, valid_frac
 
+    # ---- shard probe (N = 1 only): the shards the strong-scaling leg gives each GPU at N = 2, 4, 8, timed on this one -----
+    shard_probe = None
+    if world == 1 and not args.no_shard_probe:
+        shard_probe = {"note": "pipelined steps of vmv_validate_batch over the first n/N configurations of the batch: what "
+                               "ONE rank of the N-GPU strong-scaling leg executes per step (no exchange).  ceiling = the "
+                               "1-GPU step time / the shard's step time = the most N GPUs can gain on the 1M job before "
+                               "any exchange cost; no N > 1 run has been measured on hardware", "shards": {}}
+        for parts in (2, 4, 8):
+            lo, hi = shard_range(n, 0, parts)
+            m = hi - lo
+            dt_shard, _ = run(q[:m], m, (m + 63) // 64, args.steps, max(3, args.warmup // 4), None)
+            shard_probe["shards"][str(parts)] = {"configs": m, "ms_per_step": dt_shard / args.steps * 1e3,
+                                                 "ceiling": (elapsed / args.steps) / (dt_shard / args.steps)}
+
     # ---- informational: independent batches on two streams (N = 1 only; never `value`) ------------------------------
     two_streams = None
     if world == 1 and not args.no_two_streams:
@@ -356,6 +371,8 @@ def main():
                                  "is reported because the metric asks for it (DESIGN.md §5)"},
             "kernel_checks_per_s": n / ((kernel_ms + self_ms) * 1e-3),
         }
+        if shard_probe is not None:
+            out["shard_probe"] = shard_probe
         if two_streams is not None:
             out["two_streams"] = two_streams
         if world == 1 and not args.no_cpu_baseline:

@@ -194,7 +194,9 @@ int vmv_validate_batch_host(int robot, const vmv_env *env, const float *q, size_
 int vmv_validate_motion_batch_host(int robot, const vmv_env *env, const float *start, const float *goal, size_t n,
                                    uint64_t *bits);
 /* The host-buffer variants stage through a per-thread device arena that is reused between calls (requests above 64 MiB
- * are not kept).  Frees the calling thread's arena; optional — the arena is never touched at thread or process exit. */
+ * are not kept), and vmv_validate_motion_batch keeps 8 bytes of device scratch per edge per (device, stream) for its task
+ * lists.  Frees the calling thread's arena and every stream's scratch (waits for edge batches in flight); optional — none
+ * of this memory is touched at thread or process exit. */
 int vmv_release_staging(void);
 
 /* ---- multi-GPU: one process per GPU, every unit independent given the read-only environment ------- */

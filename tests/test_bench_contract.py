@@ -39,7 +39,11 @@ def test_bench_line_single_gpu():
     assert d["value"] > 1e8  # the north-star floor, by a wide margin
     two = d["two_streams"]  # informational leg: the same steps on two alternating streams, never `value`
     assert two["same_words_as_the_timed_run"] is True and two["value"] > 0 and two["unit"] == d["unit"]
-    assert "two_streams" not in _run("--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--no-two-streams")
+    probe = d["shard_probe"]["shards"]  # the N = 2, 4, 8 shards of the 1M job timed on this GPU
+    assert set(probe) == {"2", "4", "8"} and probe["8"]["configs"] == d["config"]["configs_per_gpu"] // 8
+    assert all(p["ms_per_step"] > 0 and 0.5 < p["ceiling"] <= int(k) * 1.5 for k, p in probe.items())
+    short = _run("--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--no-two-streams", "--no-shard-probe")
+    assert "two_streams" not in short and "shard_probe" not in short
 
 
 @pytest.mark.gpu

@@ -66,6 +66,33 @@ def test_validate_motion_batch_bit_exact(vamp, oracle, name, kind):
                           oracle.validate_motion_batch(rid, oenv, a, b, threads=8))
 
 
+@pytest.mark.parametrize("name", ROBOTS)
+@pytest.mark.parametrize("kind", ["shell64", "mixed", "capt", "attach", "heightfield"])
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_edge_schedules_are_bit_exact(vamp, oracle, monkeypatch, name, kind, mode):
+    """vmv_validate_motion_batch has three schedules (csrc/vmv_robot_tu.inc: launch_validate_motion): 0 = one rake group
+    walks one edge, 1 = (edge, rake) tasks in two passes, 2 = tasks in doubling passes.  Each is forced here (the default
+    picks by batch size) on edges of every length — zero-length ones, one-rake ones, edges of dozens of rakes — with
+    ragged batch sizes around the 8-edge waves and 64-edge words, and must give the oracle's booleans."""
+    monkeypatch.setenv("VMV_EDGE_TASKS", str(mode))
+    env, oenv = make_env(kind, oracle, name)
+    mod = getattr(vamp, name)
+    n = 1100 if kind != "capt" else 500
+    rid, a, b, want = mixed_edges(oracle, name, oenv, n, case_seed(name, kind, "schedules"), zero_every=5)
+    _non_degenerate(want, n)
+    assert np.array_equal(mod.validate_motion_batch(a, b, env), want)
+    for m in (1, 7, 8, 9, 63, 64, 65, 100):
+        assert np.array_equal(mod.validate_motion_batch(a[:m], b[:m], env), want[:m])
+    # long edges between valid postures (many rakes, collisions at every rake index) and between uniform configurations
+    rid, q, ok = mixed_configs(oracle, name, oenv, 600, case_seed(name, kind, "schedule-ends"))
+    ends = q[ok][:256] if ok.sum() >= 32 else q[:256]
+    la, lb = ends[: len(ends) // 2], ends[len(ends) // 2: 2 * (len(ends) // 2)]
+    assert np.array_equal(mod.validate_motion_batch(la, lb, env), oracle.validate_motion_batch(rid, oenv, la, lb, threads=8))
+    rid, ua = uniform_configs(oracle, name, 300, seed=17)
+    ub = (ua + np.random.default_rng(18).normal(0, 0.5, ua.shape)).astype(np.float32)
+    assert np.array_equal(mod.validate_motion_batch(ua, ub, env), oracle.validate_motion_batch(rid, oenv, ua, ub, threads=8))
+
+
 @pytest.mark.parametrize("name,kind", [("fetch", "config3"), ("baxter", "config5"), ("panda", "config3"), ("ur5", "config5")])
 def test_baseline_point_cloud_configs_at_cloud_size(vamp, oracle, name, kind):
     """BASELINE config 3 (Fetch vs a 10,000-point CAPT cloud) and config 5 (Baxter edges vs 32 primitives + a
@@ -578,6 +605,19 @@ def test_full_size_baseline_configs(vamp, oracle, cfg):
     if edges:  # an edge whose every rake is valid has a valid goal configuration (lane 7 of the first rake is the goal)
         goal_ok = mod.validate_batch(tb, env).cpu().numpy()
         assert not np.any(v & ~goal_ok)
+        for mode in ("0", "1", "2"):  # the three edge schedules give the same words at full size (1M edges = one slice)
+            os.environ["VMV_EDGE_TASKS"] = mode
+            try:
+                assert np.array_equal(run(ta, tb), v), f"VMV_EDGE_TASKS={mode}"
+            finally:
+                del os.environ["VMV_EDGE_TASKS"]
+        if cfg == "config4":  # more than one slice of 2^20 edges through the task schedule
+            os.environ["VMV_EDGE_TASKS"] = "1"
+            try:
+                xa, xb = torch.cat([ta, ta[:777]]).contiguous(), torch.cat([tb, tb[:777]]).contiguous()
+                assert np.array_equal(run(xa, xb), np.concatenate([v, v[:777]]))
+            finally:
+                del os.environ["VMV_EDGE_TASKS"]
     # sampled oracle parity at full size
     m = 40000 if cfg == "config3" else (20000 if base == "config4" else 4000)
     idx = np.random.default_rng(2).choice(n, m, replace=False)

@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--scale", type=float, default=1.0, help="fraction of the BASELINE batch sizes (smoke runs)")
+    ap.add_argument("--shard-probe", action="store_true", help="1 GPU: also time the N = 2, 4, 8 shards of the batch")
     ap.add_argument("--stats", action="store_true", help="edges: also report rakes per edge / rakes walked per edge")
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -162,12 +163,26 @@ def main():
             t = torch.tensor([dt], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
+        probe = None
+        if world == 1 and args.shard_probe:  # what ONE rank of the N-GPU job executes per step, timed on this GPU
+            probe = {}
+            for parts in (2, 4, 8):
+                lo_p, hi_p = shard_range(n, 0, parts)
+                sa, sb = a[lo_p:hi_p].contiguous(), None if b is None else b[lo_p:hi_p].contiguous()
+                validate_batch_sharded(mod, sa, env, goals=sb, rank=0, world=1)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(args.iters * 4):
+                    validate_batch_sharded(mod, sa, env, goals=sb, rank=0, world=1)
+                torch.cuda.synchronize()
+                ms = (time.perf_counter() - t0) / (args.iters * 4) * 1e3
+                probe[str(parts)] = {"units": hi_p - lo_p, "ms": ms, "ceiling": (dt / args.iters * 1e3) / ms}
         if rank == 0:
             valid = vamp.unpack_bits(words.cpu().numpy().view(np.uint64), n)
             lo, hi = shard_range(n, 0, world)
             print(json.dumps({"config": cfg, "robot": mod._name, "n": n, "n_gpus": world, "ms": dt / args.iters * 1e3,
                               "value": n * args.iters / dt, "unit": unit, "scaling": "strong",
-                              "valid_fraction": float(valid.mean()), "shard0": [lo, hi], "workload": shape, "rakes": stats,
+                              "valid_fraction": float(valid.mean()), "shard0": [lo, hi], "workload": shape, "rakes": stats, "shard_probe": probe,
                               "exchange": "RCCL all_gather of packed validity words" if world > 1 else "none"}), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -26,7 +26,12 @@ ua = (lo + (hi - lo) * torch.rand((N, 6), generator=g, device="cuda")).contiguou
 d = torch.randn((N, 6), generator=g, device="cuda")
 ub = (ua + d / d.norm(dim=1, keepdim=True) * (0.2 + 1.3 * torch.rand((N, 1), generator=g, device="cuda"))).contiguous()
 sizes = [int(x) for x in sys.argv[1:]] or [256, 2048, 16384, 131072, 262144, 524288, N]
-for shape, A, B in (("prm", pa, pb), ("uniform", ua, ub)):
+modes = os.environ.get("EDGE_MODES", "default").split(",")  # VMV_EDGE_TASKS values to compare (default = by batch size)
+for shape, A, B, mode in ((s, x, y, m) for (s, x, y) in (("prm", pa, pb), ("uniform", ua, ub)) for m in modes):
+    if mode == "default":
+        os.environ.pop("VMV_EDGE_TASKS", None)
+    else:
+        os.environ["VMV_EDGE_TASKS"] = mode
     for n in sizes:
         a, b = A[:n].contiguous(), B[:n].contiguous()
         bits = torch.zeros((n + 63) // 64, dtype=torch.int64, device="cuda")
@@ -45,5 +50,5 @@ for shape, A, B in (("prm", pa, pb), ("uniform", ua, ub)):
             torch.cuda.synchronize()
         ds = (time.perf_counter() - t0) / 10
         valid = float(vamp.unpack_bits(bits.cpu().numpy().view("uint64"), n).mean())
-        print(f"{shape:8s} {n:8d} edges: {dt * 1e3:8.4f} ms/step  {n / dt:.3e} edges/s   sync {ds * 1e3:8.4f} ms   valid {valid:.3f}",
+        print(f"{shape:8s} mode {mode:8s} {n:8d} edges: {dt * 1e3:8.4f} ms/step  {n / dt:.3e} edges/s   sync {ds * 1e3:8.4f} ms   valid {valid:.3f}",
               flush=True)

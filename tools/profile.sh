@@ -7,7 +7,7 @@
 # Copy the summaries you want judged from gpurun_out/$TAG into profiles/.
 set -o pipefail
 TAG=${1:-prof}; shift
-ARGS=${@:---steps 30 --warmup 5 --no-cpu-baseline --no-two-streams}
+ARGS=${@:---steps 30 --warmup 5 --no-cpu-baseline --no-two-streams --no-shard-probe}
 PROG=${PROFILE_PROG:-bench.py}   # e.g. PROFILE_PROG=tools/bench_configs.py bash tools/profile.sh r02_config3 config3
 OUT=gpurun_out/$TAG
 mkdir -p $OUT

@@ -1164,6 +1164,7 @@ extern "C"
     int vmv_release_staging(void)
     {
         g_staging.release();
+        vmv::release_edge_scratch();  // (waits for the edge batches still in flight: hipFree synchronizes)
         return VMV_OK;
     }
     int vmv_validate_batch_host(int robot, const vmv_env *env, const float *q, size_t n, uint64_t *bits)

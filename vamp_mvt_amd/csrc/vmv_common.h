@@ -5,6 +5,8 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <mutex>
+
 #include "vmv_device.h"
 
 namespace vmv
@@ -43,4 +45,29 @@ namespace vmv
     extern const RobotLaunchers kPandaLaunchers, kUr5Launchers, kFetchLaunchers, kBaxterLaunchers;
 
     int hip_status(hipError_t e, const char *what);  // records vmv_last_error(), maps to VMV_ERR_*
+
+    // ---- (edge, rake) task scheduling of vmv_validate_motion_batch: the robot-independent half (vmv_edge_tasks.hip) ----
+    constexpr uint32_t kEdgeScanBlock = 2048;        // edges per workgroup of the scan kernels
+    constexpr uint32_t kEdgeSliceEdges = 1u << 20;   // a larger batch is validated slice by slice (32-bit task arithmetic)
+    constexpr uint32_t kEdgeMaxPasses = 8;
+    struct EdgeScratch
+    {
+        uint32_t *steps;       // [n] rakes of edge e (planning/validate.hh:41), written by pass 0
+        uint32_t *excl;        // [n] exclusive scan of the current pass's task counts
+        uint32_t *block_sums;  // [ceil(n / kEdgeScanBlock)]
+        uint32_t *total;       // [kEdgeMaxPasses] tasks of each pass
+    };
+    class EdgeScratchLease
+    {
+        std::unique_lock<std::mutex> lock_;
+
+    public:
+        EdgeScratch s{};
+        EdgeScratchLease();
+        int acquire(hipStream_t stream, size_t n_edges);  // holds the pool until the lease goes out of scope
+    };
+    void release_edge_scratch();
+    // task counts of the pass that covers rakes [lo, hi) of the edges still valid in d_bits -> s.excl, s.total[slot]
+    int launch_edge_pass_scan(const EdgeScratch &s, const uint64_t *d_bits, uint32_t n, uint32_t lo, uint32_t hi, uint32_t slot,
+                              hipStream_t stream);
 }  // namespace vmv
