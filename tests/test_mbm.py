@@ -3,18 +3,28 @@ tools/make_mbm_golden.py): the one reference-held fixture family with capsules a
 
 Known answers (resources/README.md:146,81,210, the seven scenario families of README.md:24, validity rule
 resources/problem_tar_to_pkl_json.py:79-84 = start valid and some goal valid, scene mapping src/vamp/__init__.py:140-186):
-    Panda 699 / 700 - REPRODUCED exactly by the oracle and by the HIP path.
-    UR5   608 / 700 published, 689 / 700 here;  Fetch 679 / 700 published, 671 / 700 here.
-The UR5 / Fetch differences are a finding, not tuned away: joint order equals the reference's
-`joint_names`, FK is bit-exact against the reference's generated fkcc for every sphere, a joint-bounds check changes
-nothing for UR5, and all ten invalid UR5 goals are self-collisions.  The archive in this checkout holds 13 scenario
-families where the README's tables speak of 7 x 100 problems, i.e. the published tables were produced from an earlier
-vintage of the data (and possibly of the robot models).  The counts below are therefore: Panda = reference pin;
-UR5 / Fetch = this restatement's answers, kept so that oracle and HIP path are compared on capsules and rotated cuboids
-of real scenes, with the published numbers recorded next to them.
+    Panda 699 / 700 - REPRODUCED exactly by the oracle and by the HIP path: the only one of the three that is a pin.
+    UR5   608 / 700 published, 689 / 700 here;  Fetch 679 / 700 published, 671 / 700 here:
+    **parity unpinned: reference-held answer not reproduced, cause unproven.**
+For UR5 and Fetch, oracle == HIP agreement on these scenes shows self-consistency (on capsules and rotated cuboids of
+real scenes), not reference parity.  What is recorded so that a reader with the real reference can check it
+(tools/mbm_diagnostics.py -> tests/golden/mbm_diagnostics.json, re-derived by test_mbm_diagnostics_are_current):
+  * per family: start-valid / goal-valid / both (PER_FAMILY below);
+  * per invalid problem: endpoint, the predicate that fires (self-collision link pair or scene object) and the deepest
+    penetration: every one of the 1 + 11 + 29 invalid problems is a graze of 0.03 - 8.9 mm, none is a deep overlap
+    (UR5: ten goals with forearm x wrist_2/3 self-collisions of 0.7 - 8.9 mm + one start 2.4 mm into a cuboid; Fetch: 22
+    goals 0.03 - 5.9 mm into a shelf board or pole, two head_pan x upperarm_roll goals at 1.0 mm, five starts with
+    base_link self-collisions of 0.5 - 5.8 mm);
+  * the near misses among the problems valid here: 81 UR5 problems have an environment gap below 5 mm (6 below 2 mm) -
+    exactly the size of the UR5 gap (689 - 608 = 81) - and 9 of Fetch's 29 invalid problems are grazes of <= 1 mm
+    (679 - 671 = 8).  Both gaps are thus of the size that millimetre-level differences in the scene data or the sphere
+    models produce; which of the two it is cannot be told offline (the archive in this checkout holds 13 scenario
+    families where the README's tables speak of 7 x 100 problems; FK and group tables here are bit-identical to the
+    shipped headers; joint order equals the reference's `joint_names`; a joint-bounds check changes nothing for UR5).
 
 This is a tolerance-level pin: Euler angles are recomputed from the scene quaternions and the euler -> axes
 constructors are this package's fp32 restatement of collision/factory.hh (the reference uses Eigen)."""
+import json
 import os
 
 import numpy as np
@@ -22,7 +32,16 @@ import pytest
 
 STANDARD = ["bookshelf_small", "bookshelf_tall", "bookshelf_thin", "box", "cage", "table_pick", "table_under_pick"]
 PUBLISHED = {"panda": 699, "ur5": 608, "fetch": 679}   # resources/README.md:146,81,210
-HERE = {"panda": 699, "ur5": 689, "fetch": 671}        # oracle == HIP path; see the module docstring
+HERE = {"panda": 699, "ur5": 689, "fetch": 671}        # oracle == HIP path; UR5 / Fetch: parity unpinned (module docstring)
+# valid starts / valid goals / both, of 100 problems per family (oracle; the reference's rule counts "both")
+PER_FAMILY = {
+    "panda": {"bookshelf_small": (100, 100, 100), "bookshelf_tall": (100, 100, 100), "bookshelf_thin": (100, 100, 100),
+              "box": (100, 100, 100), "cage": (100, 100, 100), "table_pick": (100, 99, 99), "table_under_pick": (100, 100, 100)},
+    "ur5": {"bookshelf_small": (100, 96, 96), "bookshelf_tall": (100, 95, 95), "bookshelf_thin": (100, 99, 99),
+            "box": (100, 100, 100), "cage": (100, 100, 100), "table_pick": (100, 100, 100), "table_under_pick": (99, 100, 99)},
+    "fetch": {"bookshelf_small": (100, 98, 98), "bookshelf_tall": (100, 96, 96), "bookshelf_thin": (100, 84, 84),
+              "box": (100, 99, 99), "cage": (100, 99, 99), "table_pick": (100, 100, 100), "table_under_pick": (95, 100, 95)},
+}
 
 
 def _load(golden_dir, robot):
@@ -63,6 +82,30 @@ def test_oracle_mbm_validity_counts(vamp, oracle, golden_dir, robot):
     assert valid == HERE[robot]
     if robot == "panda":
         assert valid == PUBLISHED[robot]
+
+
+@pytest.mark.parametrize("robot", ["panda", "ur5", "fetch"])
+def test_mbm_diagnostics_are_current(vamp, oracle, golden_dir, robot):
+    """tests/golden/mbm_diagnostics.json (per-family table, the predicate and penetration depth of every invalid problem,
+    near-miss counts) is what tools/mbm_diagnostics.py derives from the oracle today, and says what the module docstring
+    says: every invalid problem is a graze below 1 cm, and 81 UR5 problems sit within 5 mm of the environment."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools"))
+    from mbm_diagnostics import diagnose
+
+    committed = json.load(open(os.path.join(golden_dir, "mbm_diagnostics.json")))
+    now = json.loads(json.dumps(diagnose(vamp, oracle, golden_dir, robot)))
+    assert now == committed[robot]
+    assert now["valid"] == HERE[robot] and committed["published"][robot] == PUBLISHED[robot]
+    for fam, (s_ok, g_ok, both) in PER_FAMILY[robot].items():
+        row = now["families"][fam]
+        assert (row["start_valid"], row["goal_valid"], row["both"], row["problems"]) == (s_ok, g_ok, both, 100)
+    assert len(now["invalid"]) >= 700 - HERE[robot]
+    for e in now["invalid"]:
+        assert e["cause"] in ("self", "environment", "self+environment")
+        assert 0.0 < max(e["self_depth_m"], e["env_depth_m"]) < 0.01, e  # grazes, not deep overlaps
+    if robot == "ur5":
+        assert now["near_misses"]["environment_gap_below_5mm"] == HERE["ur5"] - PUBLISHED["ur5"] == 81
 
 
 @pytest.mark.gpu
