@@ -109,14 +109,14 @@ def _cpu_model():
 
 
 def pmc_profile():
-    """profiles/r02_pmc.json (tools/profile.sh + tools/make_pmc_profile.py) if it was measured on THIS build"""
-    path = os.path.join(ROOT, "profiles", "r02_pmc.json")
+    """profiles/r03_pmc.json (tools/profile.sh + tools/make_pmc_profile.py) if it was measured on THIS build"""
+    path = os.path.join(ROOT, "profiles", "r03_pmc.json")
     try:
         with open(path) as f:
             prof = json.load(f)
         current = _load_by_path("source_hash", os.path.join(ROOT, "tools", "source_hash.py")).source_hash()
         if prof.get("source_hash") != current:
-            return None, f"profiles/r02_pmc.json was measured on build {prof.get('source_hash')}, this is {current}"
+            return None, f"profiles/r03_pmc.json was measured on build {prof.get('source_hash')}, this is {current}"
         return prof, None
     except (OSError, ValueError) as e:
         return None, f"no PMC summary: {e}"
@@ -338,7 +338,7 @@ def main():
                         "lane_utilisation": k["SQ_THREAD_CYCLES_VALU"] / (k["SQ_ACTIVE_INST_VALU"] * 64.0)}
             valu = {"peak": "1 wave64 VALU instruction per 2 cycles per SIMD, 1,024 SIMDs at 2.4 GHz (157 TFLOP/s fp32 vector)",
                     "validate_env_kernel": valu_of(ke, kernel_ms), "validate_self_kernel": valu_of(ks, self_ms),
-                    "source": prof.get("source", "profiles/r02_pmc.json")}
+                    "source": prof.get("source", "profiles/r03_pmc.json")}
         out = {
             "metric": "config collision checks/sec (Panda, 64-prim env)",
             "value": value,

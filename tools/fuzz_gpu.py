@@ -106,6 +106,12 @@ def main():
             os.environ["VMV_SELF_GROUP"] = str(group)
         else:
             os.environ.pop("VMV_SELF_GROUP", None)
+        # the edge schedule (vmv_robot_tu.inc: launch_validate_motion): the default most of the time, the others too
+        sched = rng.choice(["", "", "", "0", "1", "2"])
+        if sched:
+            os.environ["VMV_EDGE_TASKS"] = str(sched)
+        else:
+            os.environ.pop("VMV_EDGE_TASKS", None)
         rid = o.robot(robot)
         lo, span = o.bounds(rid)
         mod = getattr(vamp, robot)
@@ -140,7 +146,7 @@ def main():
         totals["configs"] += n
         totals["edges"] += m
         kinds = sorted({k for k, _ in spec})
-        print(f"case {case} seed {seed} {robot}: {len(spec)} objects {kinds} | configs {n} valid {int(want.sum())} "
+        print(f"case {case} seed {seed} {robot} sched {sched or '-'}: {len(spec)} objects {kinds} | configs {n} valid {int(want.sum())} "
               f"{'ok' if ok else 'MISMATCH'} | edges {m} valid {int(want_e.sum())} {'ok' if ok_e else 'MISMATCH'} | "
               f"spheres {'ok' if ok_s else 'MISMATCH'}", flush=True)
         if not (ok and ok_e and ok_s):

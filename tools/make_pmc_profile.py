@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""rocprofv3 PMC summary (tools/pmc_summary.py --json) -> profiles/r02_pmc.json, the file bench.py quotes in its
+"""rocprofv3 PMC summary (tools/pmc_summary.py --json) -> profiles/r03_pmc.json, the file bench.py quotes in its
 `roofline.valu` / `roofline.traffic` fields IF it was measured on the build being benched (source hash).
 
 HBM bytes per launch follow MI355X_MICROARCH.md §HBM: FETCH_SIZE and WRITE_SIZE come from separate --pmc passes, are in
@@ -29,6 +29,6 @@ out = {"source_hash": source_hash(), "configs": configs, "kernels": kernels,
        "source": f"rocprofv3 --pmc passes over `python3 bench.py --steps 30 --warmup 5 --no-cpu-baseline` ({src}); "
                  "SQ_* are per launch (averaged over the launches of the run), *_CYCLES in quad-cycles; "
                  "hbm_bytes = FETCH_SIZE KiB x 1024 x 2 (gfx950 correction) + WRITE_SIZE KiB x 1024"}
-dst = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles", "r02_pmc.json")
+dst = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles", "r03_pmc.json")
 json.dump(out, open(dst, "w"), indent=1)
 print("wrote", dst, "for build", out["source_hash"], "kernels:", sorted(kernels))

@@ -24,7 +24,7 @@ for CTRS in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU 
   echo "pmc pass $i done" >&2
 done
 python3 tools/pmc_summary.py $OUT/pmc1 $OUT/pmc2 $OUT/pmc3 $OUT/pmc4 $OUT/pmc5 $OUT/pmc6 --json $OUT/pmc.json > $OUT/pmc_summary.txt
-if [ "$PROG" = "bench.py" ]; then python3 tools/make_pmc_profile.py $OUT/pmc.json && cp profiles/r02_pmc.json $OUT/r02_pmc.json; fi
+if [ "$PROG" = "bench.py" ]; then python3 tools/make_pmc_profile.py $OUT/pmc.json && cp profiles/r03_pmc.json $OUT/r03_pmc.json; fi
 find $OUT/stats -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats.csv \;
 # keep the merge small: drop the raw traces
 find $OUT -name "*.csv" -size +2M -delete

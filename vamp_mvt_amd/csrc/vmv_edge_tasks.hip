@@ -202,8 +202,9 @@ namespace vmv
     {
         const uint32_t blocks = (n + kEdgeScanBlock - 1) / kEdgeScanBlock;
         const uint8_t *bits8 = reinterpret_cast<const uint8_t *>(d_bits);
-        hipLaunchKernelGGL(edge_block_sums_kernel, dim3(blocks), dim3(kScanThreads), 0, stream, s.steps, bits8, n, lo, hi,
-                           s.block_sums);
+        if (blocks > 1)  // (a single block has nothing before it: one launch less for planner-sized batches)
+            hipLaunchKernelGGL(edge_block_sums_kernel, dim3(blocks), dim3(kScanThreads), 0, stream, s.steps, bits8, n, lo, hi,
+                               s.block_sums);
         hipLaunchKernelGGL(edge_scan_write_kernel, dim3(blocks), dim3(kScanThreads), 0, stream, s.steps, bits8, n, lo, hi,
                            s.block_sums, s.excl, s.total + slot);
         if (hipError_t e = hipGetLastError(); e != hipSuccess) return hip_status(e, "edge pass scan");
