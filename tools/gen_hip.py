@@ -431,22 +431,11 @@ def emit_robot(m):
     L.append("")
 
     # ---- environment half of fkcc ------------------------------------------------------------------------
-    L.append("    // Environment half of Robot::fkcc<rake> (reference robots/%s.hh `fkcc`, \"environment vs. robot" % n)
-    L.append("    // collisions\"): true = some link group of this rake reports a collision.")
-    L.append("    // `skip` (rake-uniform): this rake's answer is not needed; it only keeps the lanes converged.")
-    L.append("    template <int G, int V>")
-    L.append("    __device__ __forceinline__ bool")
-    L.append("    fkcc_env(const vmv::EnvView &E, const float (&q)[kDim], vmv::lds_ptr slab, const bool skip)")
-    L.append("    {")
-    L.append("        bool bad = skip || (E.dev->static_hit != 0u);")
-    L.append("        // per-wave scratch words live right behind the sphere slab")
-    L.append("        const vmv::lds_ptr scratch = slab - __lane_id() + kSlabSpheres * 3 * vmv::kRow;")
-    L.append("        const unsigned long long skip_links = E.dev->link_skip;  // reach certificates (vmv_api.hip), wave-uniform")
     class_radii, link_class = grid_classes(m)
     static = set(static_links(m))
     reach = link_samples(m)
 
-    def emit_env_link(em, ln, lazy=LAZY_FINE_FK, no_skip=False):
+    def emit_env_link(em, ln, lazy=LAZY_FINE_FK, no_skip=False, pair_with=None, pre=None):
         """one link of the environment half: FK ops, slab staging, gate, fine chunks (appends to em.lines).
         lazy: the FK ops only this link's fine spheres need, and the staging of its first chunk, are emitted inside
         `if (wave_any(gate))` - links whose bounding sphere never reaches an obstacle (the base links in a shell-shaped
@@ -489,8 +478,21 @@ def emit_robot(m):
         if not lazy:
             for si, s in enumerate(chunks[0]):
                 stage(1 + si, s, "        ")
+        if pair_with is not None:
+            # paired variant: the point-cloud queries of this link's bounding sphere and of the next link's, together
+            # (vmv::capt_gate_pair); bit 0 = this link, bit 1 = the next one (consumed by its own gate below)
+            gb = env_by_link[pair_with]
+            em.need([gb["bound"]])
+            ca = ", ".join(em.coord(g["bound"], k) for k in range(3))
+            cb = ", ".join(em.coord(gb["bound"], k) for k in range(3))
+            em.lines.append(f"        const unsigned {pre[0]} = vmv::capt_gate_pair<G, Tab>(E, {ca}, {radii_off[ln]}, {cb}, "
+                            f"{radii_off[pair_with]}, !bad);  // {ln} + {pair_with}")
         em.lines.append("        {")
-        em.lines.append(f"            const bool gate = vmv::env_gate<G, Tab, V>(E, slab, scratch, {radii_off[ln]}, {link_class[ln]}, !bad);")
+        if pre is not None:
+            em.lines.append(f"            const bool gate = vmv::env_gate<G, Tab, V, true>(E, slab, scratch, {radii_off[ln]}, "
+                            f"{link_class[ln]}, !bad, ({pre[0]} & {pre[1]}u) != 0u);")
+        else:
+            em.lines.append(f"            const bool gate = vmv::env_gate<G, Tab, V>(E, slab, scratch, {radii_off[ln]}, {link_class[ln]}, !bad);")
         em.lines.append("            if (VMV_ABLATE_ENV >= 1) bad |= gate;  // measurement aid: no fine phase (wrong answers)")
         em.lines.append("            else if (vmv::wave_any(gate))")
         em.lines.append("            {")
@@ -511,13 +513,53 @@ def emit_robot(m):
         if guarded:
             em.lines.append("        }")
 
-    em = Emitter(m)
-    for ln in links:
-        emit_env_link(em, ln)
-    L += em.lines
-    L.append("        return bad;")
-    L.append("    }")
-    L.append("")
+    def env_function(name, template, paired):
+        L.append(f"    template <{template}>")
+        L.append("    __device__ __forceinline__ bool")
+        L.append(f"    {name}(const vmv::EnvView &E, const float (&q)[kDim], vmv::lds_ptr slab, const bool skip)")
+        L.append("    {")
+        if paired:
+            L.append("        constexpr int V = vmv::kEnvFull;")
+        else:
+            L.append("#ifndef VMV_NO_CAPT_PAIR  // (A/B knob, tools/build_variant.py: every gate queries the clouds on its own)")
+            L.append("        if constexpr (V == vmv::kEnvFull) return fkcc_env_paired<G>(E, q, slab, skip);")
+            L.append("#endif")
+        L.append("        bool bad = skip || (E.dev->static_hit != 0u);")
+        L.append("        // per-wave scratch words live right behind the sphere slab")
+        L.append("        const vmv::lds_ptr scratch = slab - __lane_id() + kSlabSpheres * 3 * vmv::kRow;")
+        if not paired:
+            L.append("        const unsigned long long skip_links = E.dev->link_skip;  // reach certificates (vmv_api.hip), wave-uniform")
+        em = Emitter(m)
+        skipped = os.environ.get("VMV_ABLATE_SKIP_LINKS", "").split(",")
+        movable = [ln for ln in links if ln not in static and ln not in skipped]
+        for ln in links:
+            if not paired or ln not in movable:
+                emit_env_link(em, ln)
+                continue
+            # links (0, 1), (2, 3), ... of the chain share one pair of point-cloud queries; reach certificates never
+            # apply to the environments this variant serves (they hold a heightfield or a point cloud), so no guards
+            i = movable.index(ln)
+            var = f"pre{i // 2}"
+            if i % 2 == 0 and i + 1 == len(movable):
+                emit_env_link(em, ln, no_skip=True)  # odd one out: queries on its own
+            elif i % 2 == 0:
+                emit_env_link(em, ln, no_skip=True, pair_with=movable[i + 1], pre=(var, 1))
+            else:
+                emit_env_link(em, ln, no_skip=True, pre=(var, 2))
+        L.extend(em.lines)
+        L.append("        return bad;")
+        L.append("    }")
+        L.append("")
+
+    L.append("    // Environment half of Robot::fkcc<rake> (reference robots/%s.hh `fkcc`, \"environment vs. robot" % n)
+    L.append("    // collisions\"): true = some link group of this rake reports a collision.")
+    L.append("    // `skip` (rake-uniform): this rake's answer is not needed; it only keeps the lanes converged.")
+    L.append("    // fkcc_env_paired: the same walk for the variant that serves environments with point clouds / heightfields")
+    L.append("    // (V = kEnvFull): the CAPT queries of the bounding spheres of two consecutive links are issued together")
+    L.append("    // (vmv::capt_gate_pair, two dependent-fetch chains in flight per wave) ahead of the first link's gate; each gate")
+    L.append("    // then takes its answer instead of querying.  Same predicates on the same spheres: the OR is unchanged.")
+    env_function("fkcc_env_paired", "int G", True)
+    env_function("fkcc_env", "int G, int V", False)
 
     # ---- static links ------------------------------------------------------------------------------------------
     L.append("    // The environment groups of the links that never move, for every lane alike: run once per (environment, robot)")

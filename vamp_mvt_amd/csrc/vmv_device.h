@@ -381,9 +381,14 @@ namespace vmv
     //      and only the lanes that pass the leaf test have any, so a per-lane walk ran at ~40 % lane utilisation for
     //      max-over-lanes iterations; re-dealt it is sum / 64 rounds.  Every point is tested with the reference's
     //      expression (sql2_3 <= (r + r_point)^2); hits are OR-ed per owner through `flags` (this wave's LDS row).
-    __device__ __forceinline__ bool
-    capt_collides(env_cptr D, const uint32_t ci, lds_cptr planes_lds, const uint32_t n_lds, lds_u32 *flags, float x, float y,
-                  float z, float r, bool active)
+    // Q queries per lane (Q = 1: a sphere; Q = 2: the bounding spheres of two consecutive links, vmv::capt_gate_pair):
+    // the stages below run for all of a lane's queries together, so the dependent fetches of one query (distance-grid
+    // cell, plane blocks, leaf record, first vector) are in flight next to the other's — the walk is a chain of memory
+    // latencies, not arithmetic.  Queries are independent: out[q] is exactly what a Q = 1 call on query q returns.
+    template <int Q>
+    __device__ __forceinline__ void
+    capt_collides_q(env_cptr D, const uint32_t ci, lds_cptr planes_lds, const uint32_t n_lds, lds_u32 *flags, const float (&x)[Q],
+                    const float (&y)[Q], const float (&z)[Q], const float (&r)[Q], const bool (&active)[Q], bool (&out)[Q])
     {
         // the cloud's header in one go (a few wide scalar loads, pinned here: left to itself the compiler sinks every
         // field behind the branch that first needs it, one scalar-cache round trip each)
@@ -398,179 +403,275 @@ namespace vmv
         const gf_cptr ax = (gf_cptr) D->capt[ci].q_x, ay = (gf_cptr) D->capt[ci].q_y, az = (gf_cptr) D->capt[ci].q_z;
         asm volatile("" ::"s"(t0), "s"(t1), "s"(t2), "s"(t3), "s"(t4), "s"(t5), "s"(r_point), "s"(cut_t0), "s"(cut_inv_step),
                      "s"(nlog2), "s"(bplanes), "s"(leaves), "s"(ax), "s"(ay), "s"(az));
-        bool inb = active;
-        inb = inb && (x + r >= t0) && (x - r <= t3);
-        inb = inb && (y + r >= t1) && (y - r <= t4);
-        inb = inb && (z + r >= t2) && (z - r <= t5);
-        if (!wave_any(inb) || VMV_ABLATE_ENV == 6) return false;
+        bool inb[Q];
+        bool any = false;
+#pragma unroll
+        for (int q = 0; q < Q; ++q)
+        {
+            out[q] = false;
+            inb[q] = active[q];
+            inb[q] = inb[q] && (x[q] + r[q] >= t0) && (x[q] - r[q] <= t3);
+            inb[q] = inb[q] && (y[q] + r[q] >= t1) && (y[q] - r[q] <= t4);
+            inb[q] = inb[q] && (z[q] + r[q] >= t2) && (z[q] - r[q] <= t5);
+            any = any || inb[q];
+        }
+        if (!wave_any(any) || VMV_ABLATE_ENV == 6) return;
         // distance grid: a centre whose cell is farther from every cloud point than r + r_point (+ 1e-4 m) cannot hit
         // whatever leaf it descends to (the leaf lists are subsets of the cloud).  The load is issued here and used after
         // the LDS part of the descent; if no lane is left, the wave skips the rest of the descent, the leaf record and the walk.
         const gf_cptr dgrid = (gf_cptr) D->capt[ci].q_dist;
-        float dist_lb = 0.0f;
+        float dist_lb[Q];
+#pragma unroll
+        for (int q = 0; q < Q; ++q) dist_lb[q] = 0.0f;
         if (dgrid != nullptr)
         {
             const float inv = D->capt[ci].dist_inv_cell;
-            const float fx = (x - D->capt[ci].dist_origin[0]) * inv, fy = (y - D->capt[ci].dist_origin[1]) * inv,
-                        fz = (z - D->capt[ci].dist_origin[2]) * inv;
             const uint32_t g0 = D->capt[ci].dist_dims[0], g1 = D->capt[ci].dist_dims[1], g2 = D->capt[ci].dist_dims[2];
-            const bool in_grid = inb && fx >= 0.0f && fy >= 0.0f && fz >= 0.0f && fx < (float) g0 && fy < (float) g1 && fz < (float) g2;
-            const size_t cell = in_grid ? ((size_t) (uint32_t) fx * g1 + (uint32_t) fy) * g2 + (uint32_t) fz : 0;
-            dist_lb = in_grid ? dgrid[cell] : 0.0f;
+#pragma unroll
+            for (int q = 0; q < Q; ++q)
+            {
+                const float fx = (x[q] - D->capt[ci].dist_origin[0]) * inv, fy = (y[q] - D->capt[ci].dist_origin[1]) * inv,
+                            fz = (z[q] - D->capt[ci].dist_origin[2]) * inv;
+                const bool in_grid = inb[q] && fx >= 0.0f && fy >= 0.0f && fz >= 0.0f && fx < (float) g0 && fy < (float) g1 &&
+                                     fz < (float) g2;
+                const size_t cell = in_grid ? ((size_t) (uint32_t) fx * g1 + (uint32_t) fy) * g2 + (uint32_t) fz : 0;
+                dist_lb[q] = in_grid ? dgrid[cell] : 0.0f;
+            }
         }
+        auto cut_by_distance = [&]() -> bool  // false: no lane of the wave has a query left
+        {
+            bool left = false;
+#pragma unroll
+            for (int q = 0; q < Q; ++q)
+            {
+                inb[q] = inb[q] && !(dist_lb[q] > (r[q] + r_point) + kCaptCutMargin);
+                left = left || inb[q];
+            }
+            return wave_any(left);
+        };
 
         // descent through the blocked copy of the planes (capt_plane_slot): three levels per step — one block of 7
         // planes fetched at once (LDS for the leading groups staged there, n_lds floats; one 32-byte read through
         // L1 / L2 below), then three compares on values already in registers.  `path` (one bit per level) is the block
         // number inside the next group and, after the last level, the leaf.
-        uint32_t path = 0u, k = 0u, base = 0u;
+        uint32_t path[Q];
+#pragma unroll
+        for (int q = 0; q < Q; ++q) path[q] = 0u;
+        uint32_t k = 0u, base = 0u;
         bool checked = false;
         for (uint32_t gs = 0u; gs < nlog2;)
         {
             const uint32_t nl = capt_group_levels(nlog2, gs);
             const uint32_t next = base + ((uint32_t) kCaptPlaneBlock << gs);
-            v4f pa, pb;
+            v4f pa[Q], pb[Q];
             if (next <= n_lds)
             {
-                const lds_v4f *b = (const lds_v4f *) (planes_lds + base + path * (uint32_t) kCaptPlaneBlock);
-                pa = b[0], pb = b[1];
+#pragma unroll
+                for (int q = 0; q < Q; ++q)
+                {
+                    const lds_v4f *b = (const lds_v4f *) (planes_lds + base + path[q] * (uint32_t) kCaptPlaneBlock);
+                    pa[q] = b[0], pb[q] = b[1];
+                }
             }
             else
             {
                 if (!checked)  // first group outside LDS: the distance bound has had the LDS groups to arrive
                 {
                     checked = true;
-                    inb = inb && !(dist_lb > (r + r_point) + kCaptCutMargin);
-                    if (!wave_any(inb)) return false;
+                    if (!cut_by_distance()) return;
                 }
-                const g_v4f *b = (const g_v4f *) (bplanes + base + (size_t) path * kCaptPlaneBlock);
-                pa = b[0], pb = b[1];
-            }
-            const float c0k = (k == 0) ? x : (k == 1) ? y : z;
-            k = (k == 2) ? 0 : k + 1;
-            const bool c0 = c0k >= pa.x;
-            path = (path << 1) | (uint32_t) c0;
-            if (nl >= 2u)
-            {
-                const float c1k = (k == 0) ? x : (k == 1) ? y : z;
-                k = (k == 2) ? 0 : k + 1;
-                const bool c1 = c1k >= (c0 ? pa.z : pa.y);
-                path = (path << 1) | (uint32_t) c1;
-                if (nl >= 3u)
+#pragma unroll
+                for (int q = 0; q < Q; ++q)
                 {
-                    const float c2k = (k == 0) ? x : (k == 1) ? y : z;
-                    k = (k == 2) ? 0 : k + 1;
-                    const float lo = c1 ? pb.x : pa.w, hi = c1 ? pb.z : pb.y;  // children of the lo child: 3, 4; of the hi child: 5, 6
-                    const bool c2 = c2k >= (c0 ? hi : lo);
-                    path = (path << 1) | (uint32_t) c2;
+                    const g_v4f *b = (const g_v4f *) (bplanes + base + (size_t) path[q] * kCaptPlaneBlock);
+                    pa[q] = b[0], pb[q] = b[1];
                 }
             }
+            const uint32_t k0 = k, k1 = (k0 == 2) ? 0 : k0 + 1, k2 = (k1 == 2) ? 0 : k1 + 1;
+#pragma unroll
+            for (int q = 0; q < Q; ++q)
+            {
+                const float c0k = (k0 == 0) ? x[q] : (k0 == 1) ? y[q] : z[q];
+                const bool c0 = c0k >= pa[q].x;
+                path[q] = (path[q] << 1) | (uint32_t) c0;
+                if (nl >= 2u)
+                {
+                    const float c1k = (k1 == 0) ? x[q] : (k1 == 1) ? y[q] : z[q];
+                    const bool c1 = c1k >= (c0 ? pa[q].z : pa[q].y);
+                    path[q] = (path[q] << 1) | (uint32_t) c1;
+                    if (nl >= 3u)
+                    {
+                        const float c2k = (k2 == 0) ? x[q] : (k2 == 1) ? y[q] : z[q];
+                        // children of the lo child: 3, 4; of the hi child: 5, 6
+                        const float lo = c1 ? pb[q].x : pa[q].w, hi = c1 ? pb[q].z : pb[q].y;
+                        const bool c2 = c2k >= (c0 ? hi : lo);
+                        path[q] = (path[q] << 1) | (uint32_t) c2;
+                    }
+                }
+            }
+            k = (k + nl) % 3u;
             base = next;
             gs += nl;
         }
         if (!checked)
         {
-            inb = inb && !(dist_lb > (r + r_point) + kCaptCutMargin);
-            if (!wave_any(inb)) return false;
+            if (!cut_by_distance()) return;
         }
-        const uint32_t zi = path;
-        if (VMV_ABLATE_ENV == 7) return zi == 0x12345u;
-        const float rr = r + r_point;
-        const float rc_sq = rr * rr;
+        if (VMV_ABLATE_ENV == 7)
+        {
+#pragma unroll
+            for (int q = 0; q < Q; ++q) out[q] = path[q] == 0x12345u;
+            return;
+        }
         // the leaf's record: box, first vector, vector count and the bucket counts in one cache line
-        const gw_cptr rec = leaves + (size_t) zi * kCaptLeafWords;
-        const g_v4f *recv = (const g_v4f *) rec;
-        const v4f r0 = recv[0], r1 = recv[1];
-        // the leaf's points are sorted by their distance to the leaf's cell (a lower bound of their distance to this
-        // centre): only the leading vectors that hold a point within r + r_point (+ 1e-4 m) can hit (vmv_capt_build.h)
-        const float bf = ((rr + kCaptCutMargin) - cut_t0) * cut_inv_step;
-        // first bucket whose threshold t0 + b * step exceeds rr + margin; radii beyond the table (and NaN: the
-        // comparison is false) take the last bucket = the whole list
-        const int b = (bf < (float) (kCaptCutBuckets - 2)) ? (int) fmaxf(floorf(bf), -1.0f) + 1 : kCaptCutBuckets - 1;
-        const uint32_t cut = (uint32_t) ((gh_cptr) (rec + 8))[b];
-        const float d0 = x - vclamp(x, r0.x, r0.w);
-        const float d1 = y - vclamp(y, r0.y, r1.x);
-        const float d2 = z - vclamp(z, r0.z, r1.y);
-        const float distsq = d0 * d0 + d1 * d1 + d2 * d2;
-        // (cut == 0: no vector can matter, same answer as walking none; in the condition so that the bucket count is
-        // fetched with the record instead of one memory latency later)
-        inb = inb && (distsq <= rc_sq) && (cut != 0u);
-        if (!wave_any(inb)) return false;
-        if (VMV_ABLATE_ENV == 8) return cut == 0x1234u;
-
-        uint32_t start = inb ? __float_as_uint(r1.z) : 0u;
-        uint32_t count = inb ? __float_as_uint(r1.w) : 0u;
-        count = (cut == 0xffffu) ? count : min(count, cut);
+        float rc_sq[Q];
+        uint32_t start[Q], count[Q];
+        any = false;
+        {
+            v4f r0[Q], r1[Q];
+            uint32_t cut[Q];
+#pragma unroll
+            for (int q = 0; q < Q; ++q)
+            {
+                const float rr = r[q] + r_point;
+                rc_sq[q] = rr * rr;
+                const gw_cptr rec = leaves + (size_t) path[q] * kCaptLeafWords;
+                const g_v4f *recv = (const g_v4f *) rec;
+                r0[q] = recv[0], r1[q] = recv[1];
+                // the leaf's points are sorted by their distance to the leaf's cell (a lower bound of their distance to
+                // this centre): only the leading vectors that hold a point within r + r_point (+ 1e-4 m) can hit
+                // (vmv_capt_build.h).  First bucket whose threshold t0 + b * step exceeds rr + margin; radii beyond the
+                // table (and NaN: the comparison is false) take the last bucket = the whole list
+                const float bf = ((rr + kCaptCutMargin) - cut_t0) * cut_inv_step;
+                const int b = (bf < (float) (kCaptCutBuckets - 2)) ? (int) fmaxf(floorf(bf), -1.0f) + 1 : kCaptCutBuckets - 1;
+                cut[q] = (uint32_t) ((gh_cptr) (rec + 8))[b];
+            }
+#pragma unroll
+            for (int q = 0; q < Q; ++q)
+            {
+                const float d0 = x[q] - vclamp(x[q], r0[q].x, r0[q].w);
+                const float d1 = y[q] - vclamp(y[q], r0[q].y, r1[q].x);
+                const float d2 = z[q] - vclamp(z[q], r0[q].z, r1[q].y);
+                const float distsq = d0 * d0 + d1 * d1 + d2 * d2;
+                // (cut == 0: no vector can matter, same answer as walking none; in the condition so that the bucket
+                // count is fetched with the record instead of one memory latency later)
+                inb[q] = inb[q] && (distsq <= rc_sq[q]) && (cut[q] != 0u);
+                any = any || inb[q];
+                start[q] = inb[q] ? __float_as_uint(r1[q].z) : 0u;
+                count[q] = inb[q] ? __float_as_uint(r1[q].w) : 0u;
+                count[q] = (cut[q] == 0xffffu) ? count[q] : min(count[q], cut[q]);
+            }
+        }
+        if (!wave_any(any)) return;
+        if (VMV_ABLATE_ENV == 8)
+        {
+#pragma unroll
+            for (int q = 0; q < Q; ++q) out[q] = count[q] == 0x1234u;
+            return;
+        }
         // every query tests its own FIRST vector (the leaf's representative point and the first afforded points) before
         // anything is re-dealt: no owner search, and a sphere well inside the cloud usually hits right there - the
         // reference's early exit for the common case
-        bool first_hit = false;
-        if (count != 0u)
+        bool first_hit[Q];
         {
-            const g_v4f *px = (const g_v4f *) (ax + 8 * (size_t) start);
-            const g_v4f *py = (const g_v4f *) (ay + 8 * (size_t) start);
-            const g_v4f *pz = (const g_v4f *) (az + 8 * (size_t) start);
-            const v4f x0 = px[0], x1 = px[1], y0 = py[0], y1 = py[1], z0 = pz[0], z1 = pz[1];
-            first_hit |= sql2_3(x0.x, y0.x, z0.x, x, y, z) <= rc_sq;
-            first_hit |= sql2_3(x0.y, y0.y, z0.y, x, y, z) <= rc_sq;
-            first_hit |= sql2_3(x0.z, y0.z, z0.z, x, y, z) <= rc_sq;
-            first_hit |= sql2_3(x0.w, y0.w, z0.w, x, y, z) <= rc_sq;
-            first_hit |= sql2_3(x1.x, y1.x, z1.x, x, y, z) <= rc_sq;
-            first_hit |= sql2_3(x1.y, y1.y, z1.y, x, y, z) <= rc_sq;
-            first_hit |= sql2_3(x1.z, y1.z, z1.z, x, y, z) <= rc_sq;
-            first_hit |= sql2_3(x1.w, y1.w, z1.w, x, y, z) <= rc_sq;
+            v4f x0[Q], x1[Q], y0[Q], y1[Q], z0[Q], z1[Q];
+#pragma unroll
+            for (int q = 0; q < Q; ++q)
+            {
+                // (a query without vectors reads vector 0 and discards it: straight-line loads, all queries in flight)
+                const size_t off = count[q] != 0u ? 8 * (size_t) start[q] : 0;
+                const g_v4f *px = (const g_v4f *) (ax + off);
+                const g_v4f *py = (const g_v4f *) (ay + off);
+                const g_v4f *pz = (const g_v4f *) (az + off);
+                x0[q] = px[0], x1[q] = px[1], y0[q] = py[0], y1[q] = py[1], z0[q] = pz[0], z1[q] = pz[1];
+            }
+#pragma unroll
+            for (int q = 0; q < Q; ++q)
+            {
+                bool h = false;
+                h |= sql2_3(x0[q].x, y0[q].x, z0[q].x, x[q], y[q], z[q]) <= rc_sq[q];
+                h |= sql2_3(x0[q].y, y0[q].y, z0[q].y, x[q], y[q], z[q]) <= rc_sq[q];
+                h |= sql2_3(x0[q].z, y0[q].z, z0[q].z, x[q], y[q], z[q]) <= rc_sq[q];
+                h |= sql2_3(x0[q].w, y0[q].w, z0[q].w, x[q], y[q], z[q]) <= rc_sq[q];
+                h |= sql2_3(x1[q].x, y1[q].x, z1[q].x, x[q], y[q], z[q]) <= rc_sq[q];
+                h |= sql2_3(x1[q].y, y1[q].y, z1[q].y, x[q], y[q], z[q]) <= rc_sq[q];
+                h |= sql2_3(x1[q].z, y1[q].z, z1[q].z, x[q], y[q], z[q]) <= rc_sq[q];
+                h |= sql2_3(x1[q].w, y1[q].w, z1[q].w, x[q], y[q], z[q]) <= rc_sq[q];
+                first_hit[q] = h && count[q] != 0u;
+                start[q] += 1u;
+                count[q] = (first_hit[q] || count[q] == 0u) ? 0u : count[q] - 1u;
+                out[q] = first_hit[q];
+            }
         }
-        start += 1u;
-        count = (first_hit || count == 0u) ? 0u : count - 1u;
-        if (!wave_any(count != 0u) || VMV_ABLATE_ENV == 9) return first_hit;
-        const uint32_t ends = wave_inclusive_scan(count);
-        const uint32_t total = (uint32_t) __builtin_amdgcn_readlane((int) ends, kWave - 1);
-        const uint32_t vbase = start - (ends - count);  // vector index of item t of this lane's query = vbase + t
+        if (VMV_ABLATE_ENV == 9) return;
         const uint32_t lane = __lane_id();
-        flags[lane] = 0u;
-        wave_lds_sync_();
-        // software-pipelined rounds: the owner search of round k + 1 (six dependent ds_bpermute) is issued while the
-        // twelve 16-byte loads of round k are in flight; the walk is bound by these latencies, not by arithmetic
-        struct Who
+        // the remaining vectors, query by query: the (lane, vector) pairs of one query index are re-dealt over the wave
+#pragma unroll
+        for (int q = 0; q < Q; ++q)
         {
-            uint32_t o, i;
-            float qx, qy, qz, qr;
-            bool act;
-        };
-        auto who = [&](const uint32_t base) -> Who
-        {
-            Who w;
-            const uint32_t t = base + lane;
-            w.act = t < total;
-            w.o = wave_upper_bound(ends, w.act ? t : 0u);
-            w.i = (uint32_t) __shfl((int) vbase, (int) w.o) + t;
-            w.qx = __shfl(x, (int) w.o), w.qy = __shfl(y, (int) w.o), w.qz = __shfl(z, (int) w.o);
-            w.qr = __shfl(rc_sq, (int) w.o);
-            return w;
-        };
-        Who cur = who(0u);
-        for (uint32_t base = 0; base < total; base += (uint32_t) kWave)
-        {
-            const size_t off = cur.act ? 8 * (size_t) cur.i : 0;  // lanes past the end read vector 0 and discard it
-            const g_v4f *px = (const g_v4f *) (ax + off);
-            const g_v4f *py = (const g_v4f *) (ay + off);
-            const g_v4f *pz = (const g_v4f *) (az + off);
-            const v4f x0 = px[0], x1 = px[1], y0 = py[0], y1 = py[1], z0 = pz[0], z1 = pz[1];
-            const Who nxt = who(base + (uint32_t) kWave);  // (past the last round: all lanes inactive, harmless)
-            bool h = false;
-            h |= sql2_3(x0.x, y0.x, z0.x, cur.qx, cur.qy, cur.qz) <= cur.qr;
-            h |= sql2_3(x0.y, y0.y, z0.y, cur.qx, cur.qy, cur.qz) <= cur.qr;
-            h |= sql2_3(x0.z, y0.z, z0.z, cur.qx, cur.qy, cur.qz) <= cur.qr;
-            h |= sql2_3(x0.w, y0.w, z0.w, cur.qx, cur.qy, cur.qz) <= cur.qr;
-            h |= sql2_3(x1.x, y1.x, z1.x, cur.qx, cur.qy, cur.qz) <= cur.qr;
-            h |= sql2_3(x1.y, y1.y, z1.y, cur.qx, cur.qy, cur.qz) <= cur.qr;
-            h |= sql2_3(x1.z, y1.z, z1.z, cur.qx, cur.qy, cur.qz) <= cur.qr;
-            h |= sql2_3(x1.w, y1.w, z1.w, cur.qx, cur.qy, cur.qz) <= cur.qr;
-            if (h && cur.act) flags[cur.o] = 1u;
-            cur = nxt;
+            if (!wave_any(count[q] != 0u)) continue;
+            const uint32_t cnt = count[q];
+            const float qx_ = x[q], qy_ = y[q], qz_ = z[q], qr_ = rc_sq[q];
+            const uint32_t ends = wave_inclusive_scan(cnt);
+            const uint32_t total = (uint32_t) __builtin_amdgcn_readlane((int) ends, kWave - 1);
+            const uint32_t vbase = start[q] - (ends - cnt);  // vector index of item t of this lane's query = vbase + t
+            flags[lane] = 0u;
+            wave_lds_sync_();
+            // software-pipelined rounds: the owner search of round k + 1 (six dependent ds_bpermute) is issued while the
+            // twelve 16-byte loads of round k are in flight; the walk is bound by these latencies, not by arithmetic
+            struct Who
+            {
+                uint32_t o, i;
+                float qx, qy, qz, qr;
+                bool act;
+            };
+            auto who = [&](const uint32_t base_t) -> Who
+            {
+                Who w;
+                const uint32_t t = base_t + lane;
+                w.act = t < total;
+                w.o = wave_upper_bound(ends, w.act ? t : 0u);
+                w.i = (uint32_t) __shfl((int) vbase, (int) w.o) + t;
+                w.qx = __shfl(qx_, (int) w.o), w.qy = __shfl(qy_, (int) w.o), w.qz = __shfl(qz_, (int) w.o);
+                w.qr = __shfl(qr_, (int) w.o);
+                return w;
+            };
+            Who cur = who(0u);
+            for (uint32_t base_t = 0; base_t < total; base_t += (uint32_t) kWave)
+            {
+                const size_t off = cur.act ? 8 * (size_t) cur.i : 0;  // lanes past the end read vector 0 and discard it
+                const g_v4f *px = (const g_v4f *) (ax + off);
+                const g_v4f *py = (const g_v4f *) (ay + off);
+                const g_v4f *pz = (const g_v4f *) (az + off);
+                const v4f x0 = px[0], x1 = px[1], y0 = py[0], y1 = py[1], z0 = pz[0], z1 = pz[1];
+                const Who nxt = who(base_t + (uint32_t) kWave);  // (past the last round: all lanes inactive, harmless)
+                bool h = false;
+                h |= sql2_3(x0.x, y0.x, z0.x, cur.qx, cur.qy, cur.qz) <= cur.qr;
+                h |= sql2_3(x0.y, y0.y, z0.y, cur.qx, cur.qy, cur.qz) <= cur.qr;
+                h |= sql2_3(x0.z, y0.z, z0.z, cur.qx, cur.qy, cur.qz) <= cur.qr;
+                h |= sql2_3(x0.w, y0.w, z0.w, cur.qx, cur.qy, cur.qz) <= cur.qr;
+                h |= sql2_3(x1.x, y1.x, z1.x, cur.qx, cur.qy, cur.qz) <= cur.qr;
+                h |= sql2_3(x1.y, y1.y, z1.y, cur.qx, cur.qy, cur.qz) <= cur.qr;
+                h |= sql2_3(x1.z, y1.z, z1.z, cur.qx, cur.qy, cur.qz) <= cur.qr;
+                h |= sql2_3(x1.w, y1.w, z1.w, cur.qx, cur.qy, cur.qz) <= cur.qr;
+                if (h && cur.act) flags[cur.o] = 1u;
+                cur = nxt;
+            }
+            wave_lds_sync_();
+            out[q] = out[q] || (inb[q] && flags[lane] != 0u);
+            wave_lds_sync_();  // (the row is cleared again for the next query)
         }
-        wave_lds_sync_();
-        return first_hit || (inb && flags[lane] != 0u);
+    }
+
+    __device__ __forceinline__ bool
+    capt_collides(env_cptr D, const uint32_t ci, lds_cptr planes_lds, const uint32_t n_lds, lds_u32 *flags, float x, float y,
+                  float z, float r, bool active)
+    {
+        const float xs[1] = {x}, ys[1] = {y}, zs[1] = {z}, rs[1] = {r};
+        const bool act[1] = {active};
+        bool out[1];
+        capt_collides_q<1>(D, ci, planes_lds, n_lds, flags, xs, ys, zs, rs, act, out);
+        return out[0];
     }
 
     // MVT::collides (collision/mvt.hh:204-279) == one lane of collides_simd (mvt.hh:282-403; lanes are
@@ -931,7 +1032,8 @@ namespace vmv
     //    run kernels without the heightfield / CAPT / MVT tail, and those without general cuboids and capsules also
     //    without those two lists (their code costs registers even when the lists are empty: 6-8 % and another 5 % on
     //    the environment kernel).
-    template <int G, int MODE, int V = kEnvFull>
+    //  * CAPT = false: the point clouds are left out (the caller holds their answer for this sphere: capt_gate_pair).
+    template <int G, int MODE, int V = kEnvFull, bool CAPT = true>
     __device__ __forceinline__ bool
     env_hit(const EnvView &E, float x, float y, float z, float r, bool active, lds_u32 *mask)
     {
@@ -970,7 +1072,7 @@ namespace vmv
             if (!wave_any(active && !hit)) break;
             hit |= active && heightfield_collides(Dp, hi, x, y, z, r);
         }
-        for (uint32_t ci = 0; ci < D.n_capt; ++ci)
+        for (uint32_t ci = 0; CAPT && ci < D.n_capt; ++ci)
         {
             const bool act = active && !hit;
             if (!wave_any(act)) break;
@@ -1060,7 +1162,7 @@ namespace vmv
     }
 
     // Gate pass of one bounding sphere through the broad-phase grid (same answer as env_hit<G, 1>).
-    template <int G, int V = kEnvFull>
+    template <int G, int V = kEnvFull, bool CAPT = true>
     __device__ __forceinline__ bool
     env_hit_grid(const EnvView &E, const uint32_t cls, float x, float y, float z, float r, bool active, lds_u32 *mask_lane)
     {
@@ -1098,7 +1200,7 @@ namespace vmv
             if (!wave_any(active && !hit)) break;
             hit |= active && heightfield_collides(Dp, hi, x, y, z, r);
         }
-        for (uint32_t ci = 0; ci < D.n_capt; ++ci)
+        for (uint32_t ci = 0; CAPT && ci < D.n_capt; ++ci)
         {
             const bool act = active && !hit;
             if (!wave_any(act)) break;
@@ -1134,10 +1236,38 @@ namespace vmv
     //              max_extent.  Hits are OR-ed back per configuration through LDS flags.
     //   env_flag   this lane's "some fine sphere of my configuration hit".
     // `active` (rake-uniform) only prunes work.  Tab::radius(i) reads the robot's __constant__ radius table.
-    template <int G, typename Tab, int V = kEnvFull>
+    // The point-cloud part of TWO gates at once (generated fkcc_env_paired): the bounding spheres of two consecutive links,
+    // both queried against every cloud with their dependent fetches interleaved (capt_collides_q<2>).  Returns this lane's
+    // answers: bit 0 = sphere a collides with a cloud, bit 1 = sphere b.  The gates then run with PRE = true: everything
+    // but the clouds, OR the bit.  (env_hit asks the clouds only when nothing else hit; asking anyway changes no OR.)
+    template <int G, typename Tab>
+    __device__ __noinline__ unsigned capt_gate_pair(const EnvView E_, float xa, float ya, float za, const int ra_index_, float xb,
+                                                    float yb, float zb, const int rb_index_, const bool active)
+    {
+        const EnvView E{uniform(E_.dev), uniform(E_.lds), uniform(E_.capt0_planes_in_lds), uniform(E_.radii)};
+        const env_cptr Dp = E.dev;
+        const uint32_t n_capt = Dp->n_capt;
+        if (n_capt == 0u) return 0u;
+        const float x[2] = {xa, xb}, y[2] = {ya, yb}, z[2] = {za, zb};
+        const float r[2] = {Tab::radius(uniform(ra_index_)), Tab::radius(uniform(rb_index_))};
+        bool hit[2] = {false, false};
+        for (uint32_t ci = 0; ci < n_capt; ++ci)
+        {
+            const bool act[2] = {active && !hit[0], active && !hit[1]};
+            if (!wave_any(act[0] || act[1])) break;
+            bool out[2];
+            capt_collides_q<2>(Dp, ci, E.lds + Dp->n_floats, (ci == 0) ? E.capt0_planes_in_lds : 0u, capt_flag_row(E), x, y, z, r,
+                               act, out);
+            hit[0] |= out[0];
+            hit[1] |= out[1];
+        }
+        return (hit[0] ? 1u : 0u) | (hit[1] ? 2u : 0u);
+    }
+
+    template <int G, typename Tab, int V = kEnvFull, bool PRE = false>
     __device__ __noinline__ bool
     env_gate(const EnvView E_, lds_cptr slab, lds_ptr scratch_, const int radius_index_, const int grid_class_,
-             const bool active)
+             const bool active, const bool pre = false /* PRE: this lane's bounding sphere collides with a point cloud */)
     {
         const uint32_t lane = __lane_id();
         const EnvView E{uniform(E_.dev), uniform(E_.lds), uniform(E_.capt0_planes_in_lds), uniform(E_.radii)};
@@ -1146,18 +1276,19 @@ namespace vmv
         if (VMV_ABLATE_ENV == 2) return slab[0] > 1e30f;  // measurement aid: FK only (keeps the FK results alive)
         bool own;
         if (E.dev->masked_fine && E.dev->grid[0].cells != nullptr)
-            own = env_hit_grid<G, V>(E, (uint32_t) uniform(grid_class_), slab[0], slab[kRow], slab[2 * kRow],
+            own = env_hit_grid<G, V, !PRE>(E, (uint32_t) uniform(grid_class_), slab[0], slab[kRow], slab[2 * kRow],
                                   Tab::radius(uniform(radius_index_)), active, mask_lane);
         else if (E.dev->masked_fine)
         {
 #pragma unroll
             for (int w = 0; w < kMaskWords; ++w) mask_lane[w * kWave] = 0u;
-            own = env_hit<G, 1, V>(E, slab[0], slab[kRow], slab[2 * kRow], Tab::radius(uniform(radius_index_)), active,
+            own = env_hit<G, 1, V, !PRE>(E, slab[0], slab[kRow], slab[2 * kRow], Tab::radius(uniform(radius_index_)), active,
                                 mask_lane);
         }
         else
-            own = env_hit<G, 0, V>(E, slab[0], slab[kRow], slab[2 * kRow], Tab::radius(uniform(radius_index_)), active,
+            own = env_hit<G, 0, V, !PRE>(E, slab[0], slab[kRow], slab[2 * kRow], Tab::radius(uniform(radius_index_)), active,
                                 nullptr);
+        if constexpr (PRE) own = own || (pre && active);
         const bool gate = group_any<G>(own);
         const uint64_t mask = __ballot(gate);
         list[kWave + lane] = 0u;  // flags
