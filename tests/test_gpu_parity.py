@@ -68,11 +68,11 @@ def test_validate_motion_batch_bit_exact(vamp, oracle, name, kind):
 
 @pytest.mark.parametrize("name", ROBOTS)
 @pytest.mark.parametrize("kind", ["shell64", "mixed", "capt", "attach", "heightfield"])
-@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
 def test_edge_schedules_are_bit_exact(vamp, oracle, monkeypatch, name, kind, mode):
-    """vmv_validate_motion_batch has three schedules (csrc/vmv_robot_tu.inc: launch_validate_motion): 0 = one rake group
-    walks one edge, 1 = (edge, rake) tasks in two passes, 2 = tasks in doubling passes.  Each is forced here (the default
-    picks by batch size) on edges of every length — zero-length ones, one-rake ones, edges of dozens of rakes — with
+    """vmv_validate_motion_batch has four schedules (csrc/vmv_robot_tu.inc: launch_validate_motion): 0 = one rake group
+    walks one edge, 1 = (edge, rake) tasks in two passes, 2 = tasks in doubling passes, 3 = two-pass tasks through the
+    fused one-FK kernel (Panda / UR5 vs primitives; elsewhere it is schedule 1).  Each is forced here on edges of every length — zero-length ones, one-rake ones, edges of dozens of rakes — with
     ragged batch sizes around the 8-edge waves and 64-edge words, and must give the oracle's booleans."""
     monkeypatch.setenv("VMV_EDGE_TASKS", str(mode))
     env, oenv = make_env(kind, oracle, name)
@@ -605,7 +605,7 @@ def test_full_size_baseline_configs(vamp, oracle, cfg):
     if edges:  # an edge whose every rake is valid has a valid goal configuration (lane 7 of the first rake is the goal)
         goal_ok = mod.validate_batch(tb, env).cpu().numpy()
         assert not np.any(v & ~goal_ok)
-        for mode in ("0", "1", "2"):  # the three edge schedules give the same words at full size (1M edges = one slice)
+        for mode in ("0", "1", "2", "3"):  # the edge schedules give the same words at full size (1M edges = one slice)
             os.environ["VMV_EDGE_TASKS"] = mode
             try:
                 assert np.array_equal(run(ta, tb), v), f"VMV_EDGE_TASKS={mode}"

@@ -107,7 +107,7 @@ def main():
         else:
             os.environ.pop("VMV_SELF_GROUP", None)
         # the edge schedule (vmv_robot_tu.inc: launch_validate_motion): the default most of the time, the others too
-        sched = rng.choice(["", "", "", "0", "1", "2"])
+        sched = rng.choice(["", "", "", "0", "1", "2", "3"])
         if sched:
             os.environ["VMV_EDGE_TASKS"] = str(sched)
         else:
