@@ -93,6 +93,49 @@ def test_edge_schedules_are_bit_exact(vamp, oracle, monkeypatch, name, kind, mod
     assert np.array_equal(mod.validate_motion_batch(ua, ub, env), oracle.validate_motion_batch(rid, oenv, ua, ub, threads=8))
 
 
+def test_edge_batches_from_two_host_threads_and_streams(vamp, oracle):
+    """vmv_validate_motion_batch is a SEQUENCE of kernels that share per-(device, stream) scratch (csrc/vmv_edge_tasks.hip):
+    two host threads, each on its own stream, and two threads on ONE stream, hammer it with batches of different sizes;
+    every result must be the oracle's (ctypes releases the GIL during the call, so the sequences really race)."""
+    import threading
+    torch = pytest.importorskip("torch")
+    env, oenv = make_env("shell64", oracle, "ur5")
+    mod = vamp.ur5
+    jobs = []
+    for i, n in enumerate((300, 5000, 70000, 1100)):
+        rid, a, b, want = mixed_edges(oracle, "ur5", oenv, min(n, 3000), case_seed("threads", str(i)), zero_every=7)
+        reps = (n + len(a) - 1) // len(a)
+        a, b, want = np.tile(a, (reps, 1))[:n], np.tile(b, (reps, 1))[:n], np.tile(want, reps)[:n]
+        jobs.append((torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda(), want))
+    errors = []
+
+    def worker(stream, order):
+        try:
+            with torch.cuda.stream(stream):
+                for _ in range(15):
+                    for j in order:
+                        ta, tb, want = jobs[j]
+                        got = mod.validate_motion_batch(ta, tb, env).cpu().numpy()
+                        if not np.array_equal(got, want):
+                            errors.append(("mismatch", j, int((got != want).sum())))
+        except Exception as e:  # noqa: BLE001
+            errors.append(("exception", repr(e)))
+
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    for streams in ((s1, s2), (s1, s1)):
+        threads = [threading.Thread(target=worker, args=(streams[0], (0, 1, 2, 3))),
+                   threading.Thread(target=worker, args=(streams[1], (3, 2, 1, 0)))]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        torch.cuda.synchronize()
+        assert not errors, errors[:3]
+    assert vamp.lib.vmv_release_staging() == 0  # frees the streams' scratch; the next call allocates again
+    ta, tb, want = jobs[0]
+    assert np.array_equal(mod.validate_motion_batch(ta, tb, env).cpu().numpy(), want)
+
+
 @pytest.mark.parametrize("name,kind", [("fetch", "config3"), ("baxter", "config5"), ("panda", "config3"), ("ur5", "config5")])
 def test_baseline_point_cloud_configs_at_cloud_size(vamp, oracle, name, kind):
     """BASELINE config 3 (Fetch vs a 10,000-point CAPT cloud) and config 5 (Baxter edges vs 32 primitives + a
