@@ -155,7 +155,11 @@ int vmv_validate_batch(int robot, const vmv_env *env, const float *d_q, size_t n
 int vmv_validate_batch_env(int robot, const vmv_env *env, const float *d_q, size_t n, uint64_t *d_bits, void *stream);
 int vmv_validate_batch_self(int robot, const float *d_q, size_t n, uint64_t *d_bits, void *stream);
 /* validate_motion<Robot, 8, Robot::resolution>(start, goal, env) — planning/validate.hh:24-77, the call every
- * planner makes per edge (rrtc.hh:136-140, prm.hh:59, fcit.hh:238 ...).  One bit per edge. */
+ * planner makes per edge (rrtc.hh:136-140, prm.hh:59, fcit.hh:238 ...).  One bit per edge.
+ * A sequence of kernels on `stream` (rake 0 of every edge, a scan, the remaining rakes of the surviving edges), with 8
+ * bytes of internal device scratch per edge kept per (device, stream); batches beyond 2^20 edges run slice by slice.
+ * Rake counts are 32-bit: the rakes of one slice must number below 2^32 (edges averaging 4,096 rakes = 512 rad at
+ * resolution 64 — far beyond any joint range; the reference's walk of such an edge would not end either). */
 int vmv_validate_motion_batch(int robot, const vmv_env *env, const float *d_start, const float *d_goal, size_t n,
                               uint64_t *d_bits, void *stream);
 

@@ -1018,6 +1018,40 @@ namespace vmv
         return neg(z - r - zhs);
     }
 
+    // The list part of the environment header (counts, block offsets, candidate-word bases), fetched ONCE per gate /
+    // fine call and pinned in SGPRs.  Read where they are used, each field was its own scalar load behind the branch
+    // that first needs it, and — the wave-level LDS hand-offs between re-dealt rounds are memory fences to the compiler —
+    // fetched again in every round: six dependent scalar-cache round trips per round of a kernel that is latency-bound.
+    // (only the three-list variant works from the pinned copy: with all five lists compiled in, fifteen more live SGPRs
+    // push the gate / fine bodies into 65 - 90 SGPR spills per kernel, so those variants read the fields where they use them)
+#define VMV_HN(T, name) ((V == kEnvZOnly) ? H.n[T] : D.n_##name)
+#define VMV_HOFF(T, name) ((V == kEnvZOnly) ? H.off[T] : D.off_##name)
+#define VMV_HWB(T, name) ((V == kEnvZOnly) ? H.wbase[T] : D.wbase_##name)
+    struct ListHdr
+    {
+        uint32_t n[5], off[5], wbase[5];  // indexed by PrimType; lists a variant does not compile in stay 0
+    };
+    template <int V, bool PIN = true>
+    __device__ __forceinline__ ListHdr load_list_hdr(const env_cptr D)
+    {
+        ListHdr H;
+#pragma unroll
+        for (int t = 0; t < 5; ++t) H.n[t] = H.off[t] = H.wbase[t] = 0u;
+        if constexpr (V == kEnvZOnly)
+        {
+            H.n[kSphere] = D->n_sphere, H.off[kSphere] = D->off_sphere, H.wbase[kSphere] = D->wbase_sphere;
+            H.n[kZCapsule] = D->n_zcapsule, H.off[kZCapsule] = D->off_zcapsule, H.wbase[kZCapsule] = D->wbase_zcapsule;
+            H.n[kZCuboid] = D->n_zcuboid, H.off[kZCuboid] = D->off_zcuboid, H.wbase[kZCuboid] = D->wbase_zcuboid;
+#ifndef VMV_NO_HDR_HOIST  // (A/B knob, tools/build_variant.py: without the pin every field is fetched where it is used;
+                          // measured on the Panda bench: environment kernel 0.1559 -> 0.1534 ms, profiles/r03_hdr_hoist_ab.txt)
+            if constexpr (PIN)
+                asm volatile("" ::"s"(H.n[kSphere]), "s"(H.n[kZCapsule]), "s"(H.n[kZCuboid]), "s"(H.off[kSphere]), "s"(H.off[kZCapsule]),
+                             "s"(H.off[kZCuboid]), "s"(H.wbase[kSphere]), "s"(H.wbase[kZCapsule]), "s"(H.wbase[kZCuboid]));
+#endif
+        }
+        return H;
+    }
+
     // sphere_environment_in_collision (collision/validity.hh:47-158) for one robot sphere, per lane.
     //  * returns this lane's own "hits something" flag; the caller folds it over the rake with group_any.
     //  * the sorted early-break is rake-wide in the reference (all 8 lanes must agree).  Lists are sorted
@@ -1035,7 +1069,7 @@ namespace vmv
     //  * CAPT = false: the point clouds are left out (the caller holds their answer for this sphere: capt_gate_pair).
     template <int G, int MODE, int V = kEnvFull, bool CAPT = true>
     __device__ __forceinline__ bool
-    env_hit(const EnvView &E, float x, float y, float z, float r, bool active, lds_u32 *mask)
+    env_hit(const EnvView &E, const ListHdr &H, float x, float y, float z, float r, bool active, lds_u32 *mask_src)
     {
         const env_cptr Dp = E.dev;
 #define D (*Dp)
@@ -1044,26 +1078,27 @@ namespace vmv
         bool hit = false;
         if constexpr (MODE == 2)
         {
-            if constexpr ((V >> kSphere) & 1) list_masked<kSphere>(E, D.n_sphere, D.off_sphere, D.wbase_sphere, x, y, z, r, rsq, ext, active, hit, mask);
-            if constexpr ((V >> kCapsule) & 1) list_masked<kCapsule>(E, D.n_capsule, D.off_capsule, D.wbase_capsule, x, y, z, r, rsq, ext, active, hit, mask);
-            if constexpr ((V >> kZCapsule) & 1) list_masked<kZCapsule>(E, D.n_zcapsule, D.off_zcapsule, D.wbase_zcapsule, x, y, z, r, rsq, ext, active, hit, mask);
-            if constexpr ((V >> kCuboid) & 1) list_masked<kCuboid>(E, D.n_cuboid, D.off_cuboid, D.wbase_cuboid, x, y, z, r, rsq, ext, active, hit, mask);
-            if constexpr ((V >> kZCuboid) & 1) list_masked<kZCuboid>(E, D.n_zcuboid, D.off_zcuboid, D.wbase_zcuboid, x, y, z, r, rsq, ext, active, hit, mask);
+            lds_u32 *const mask = mask_src;
+            if constexpr ((V >> kSphere) & 1) list_masked<kSphere>(E, VMV_HN(kSphere, sphere), VMV_HOFF(kSphere, sphere), VMV_HWB(kSphere, sphere), x, y, z, r, rsq, ext, active, hit, mask);
+            if constexpr ((V >> kCapsule) & 1) list_masked<kCapsule>(E, VMV_HN(kCapsule, capsule), VMV_HOFF(kCapsule, capsule), VMV_HWB(kCapsule, capsule), x, y, z, r, rsq, ext, active, hit, mask);
+            if constexpr ((V >> kZCapsule) & 1) list_masked<kZCapsule>(E, VMV_HN(kZCapsule, zcapsule), VMV_HOFF(kZCapsule, zcapsule), VMV_HWB(kZCapsule, zcapsule), x, y, z, r, rsq, ext, active, hit, mask);
+            if constexpr ((V >> kCuboid) & 1) list_masked<kCuboid>(E, VMV_HN(kCuboid, cuboid), VMV_HOFF(kCuboid, cuboid), VMV_HWB(kCuboid, cuboid), x, y, z, r, rsq, ext, active, hit, mask);
+            if constexpr ((V >> kZCuboid) & 1) list_masked<kZCuboid>(E, VMV_HN(kZCuboid, zcuboid), VMV_HOFF(kZCuboid, zcuboid), VMV_HWB(kZCuboid, zcuboid), x, y, z, r, rsq, ext, active, hit, mask);
         }
         else
         {
             constexpr bool MASK = (MODE == 1);
             const float ext_wave = wave_max_nonneg(active ? ext : 0.0f);
-            if constexpr ((V >> kSphere) & 1) list_full<G, kSphere, MASK>(E, D.n_sphere, D.off_sphere, D.off_md_sphere, D.wbase_sphere, x, y, z, r, rsq, ext,
-                                        ext_wave, hit, mask);
-            if constexpr ((V >> kCapsule) & 1) list_full<G, kCapsule, MASK>(E, D.n_capsule, D.off_capsule, D.off_md_capsule, D.wbase_capsule, x, y, z, r, rsq,
-                                         ext, ext_wave, hit, mask);
-            if constexpr ((V >> kZCapsule) & 1) list_full<G, kZCapsule, MASK>(E, D.n_zcapsule, D.off_zcapsule, D.off_md_zcapsule, D.wbase_zcapsule, x, y, z, r,
-                                          rsq, ext, ext_wave, hit, mask);
-            if constexpr ((V >> kCuboid) & 1) list_full<G, kCuboid, MASK>(E, D.n_cuboid, D.off_cuboid, D.off_md_cuboid, D.wbase_cuboid, x, y, z, r, rsq, ext,
-                                        ext_wave, hit, mask);
-            if constexpr ((V >> kZCuboid) & 1) list_full<G, kZCuboid, MASK>(E, D.n_zcuboid, D.off_zcuboid, D.off_md_zcuboid, D.wbase_zcuboid, x, y, z, r, rsq,
-                                         ext, ext_wave, hit, mask);
+            if constexpr ((V >> kSphere) & 1) list_full<G, kSphere, MASK>(E, VMV_HN(kSphere, sphere), VMV_HOFF(kSphere, sphere), D.off_md_sphere, VMV_HWB(kSphere, sphere), x, y, z, r, rsq, ext,
+                                        ext_wave, hit, mask_src);
+            if constexpr ((V >> kCapsule) & 1) list_full<G, kCapsule, MASK>(E, VMV_HN(kCapsule, capsule), VMV_HOFF(kCapsule, capsule), D.off_md_capsule, VMV_HWB(kCapsule, capsule), x, y, z, r, rsq,
+                                         ext, ext_wave, hit, mask_src);
+            if constexpr ((V >> kZCapsule) & 1) list_full<G, kZCapsule, MASK>(E, VMV_HN(kZCapsule, zcapsule), VMV_HOFF(kZCapsule, zcapsule), D.off_md_zcapsule, VMV_HWB(kZCapsule, zcapsule), x, y, z, r,
+                                          rsq, ext, ext_wave, hit, mask_src);
+            if constexpr ((V >> kCuboid) & 1) list_full<G, kCuboid, MASK>(E, VMV_HN(kCuboid, cuboid), VMV_HOFF(kCuboid, cuboid), D.off_md_cuboid, VMV_HWB(kCuboid, cuboid), x, y, z, r, rsq, ext,
+                                        ext_wave, hit, mask_src);
+            if constexpr ((V >> kZCuboid) & 1) list_full<G, kZCuboid, MASK>(E, VMV_HN(kZCuboid, zcuboid), VMV_HOFF(kZCuboid, zcuboid), D.off_md_zcuboid, VMV_HWB(kZCuboid, zcuboid), x, y, z, r, rsq,
+                                         ext, ext_wave, hit, mask_src);
         }
         hit = hit && active;
         if constexpr (((V >> 5) & 1) == 0) return hit;
@@ -1086,6 +1121,14 @@ namespace vmv
         }
         return hit;
 #undef D
+    }
+    // (callers outside the hot loops: the header is fetched here)
+    template <int G, int MODE, int V = kEnvFull, bool CAPT = true>
+    __device__ __forceinline__ bool
+    env_hit(const EnvView &E, float x, float y, float z, float r, bool active, lds_u32 *mask)
+    {
+        const ListHdr H = load_list_hdr<V, false>(E.dev);
+        return env_hit<G, MODE, V, CAPT>(E, H, x, y, z, r, active, mask);
     }
 
     // Contact report (Robot::fkcc_debug -> sphere_environment_get_collisions, collision/validity.hh:161-256): which
@@ -1164,35 +1207,39 @@ namespace vmv
     // Gate pass of one bounding sphere through the broad-phase grid (same answer as env_hit<G, 1>).
     template <int G, int V = kEnvFull, bool CAPT = true>
     __device__ __forceinline__ bool
-    env_hit_grid(const EnvView &E, const uint32_t cls, float x, float y, float z, float r, bool active, lds_u32 *mask_lane)
+    env_hit_grid(const EnvView &E, const ListHdr &H, const uint32_t cls, float x, float y, float z, float r, bool active,
+                 lds_u32 *mask_lane)
     {
         const env_cptr Dp = E.dev;
 #define D (*Dp)
         const GridDev __attribute__((address_space(4))) *Gd = &Dp->grid[cls];
+        // the grid's header in one go, pinned (as the list header: otherwise one scalar round trip per field, in sequence)
+        const float inv_cell = Gd->inv_cell, o0 = Gd->origin[0], o1 = Gd->origin[1], o2 = Gd->origin[2];
+        const uint32_t d0 = Gd->dims[0], d1 = Gd->dims[1], d2 = Gd->dims[2], gw = D.grid_words;
+        const gu_cptr cells = (gu_cptr) Gd->cells;
+        if constexpr (V == kEnvZOnly)
+            asm volatile("" ::"s"(inv_cell), "s"(o0), "s"(o1), "s"(o2), "s"(d0), "s"(d1), "s"(d2), "s"(gw), "s"(cells));
         const float ext = group_max<G>(sqrtf(dot3(x, y, z, x, y, z)) + r);
         const float rsq = r * r;
         // this lane's cell; outside the grid box nothing can be touched (vmv_grid_build.h)
-        const float inv_cell = Gd->inv_cell;
-        const float fx = (x - Gd->origin[0]) * inv_cell, fy = (y - Gd->origin[1]) * inv_cell, fz = (z - Gd->origin[2]) * inv_cell;
-        const uint32_t d1 = Gd->dims[1], d2 = Gd->dims[2];
-        const bool inside = active && fx >= 0.0f && fy >= 0.0f && fz >= 0.0f && fx < (float) Gd->dims[0] && fy < (float) d1 &&
+        const float fx = (x - o0) * inv_cell, fy = (y - o1) * inv_cell, fz = (z - o2) * inv_cell;
+        const bool inside = active && fx >= 0.0f && fy >= 0.0f && fz >= 0.0f && fx < (float) d0 && fy < (float) d1 &&
                             fz < (float) d2;
         const uint32_t ix = inside ? (uint32_t) fx : 0u, iy = inside ? (uint32_t) fy : 0u, iz = inside ? (uint32_t) fz : 0u;
-        const gu_cptr cell = (gu_cptr) Gd->cells + ((size_t) (ix * d1 + iy) * d2 + iz) * D.grid_words;
+        const gu_cptr cell = cells + ((size_t) (ix * d1 + iy) * d2 + iz) * gw;
         bool hit = false;
         // all candidate words of the cell at once (independent loads, one memory latency per gate instead of one per
         // list and word: the walks below were waiting on these loads, not on arithmetic)
         static_assert(kMaskWords == 4, "list_grid selects among four preloaded words");
         uint32_t cw[kMaskWords];
-        const uint32_t gw = D.grid_words;
 #pragma unroll
         for (int w = 0; w < kMaskWords; ++w) cw[w] = (inside && (uint32_t) w < gw) ? cell[w] : 0u;
         if (VMV_ABLATE_ENV == 3) return inside && cw[0] == 0x12345u;  // measurement aid: gate overhead without the walks
-        if constexpr ((V >> kSphere) & 1) list_grid<kSphere>(E, D.n_sphere, D.off_sphere, D.wbase_sphere, cw, x, y, z, r, rsq, ext, hit, mask_lane);
-        if constexpr ((V >> kCapsule) & 1) list_grid<kCapsule>(E, D.n_capsule, D.off_capsule, D.wbase_capsule, cw, x, y, z, r, rsq, ext, hit, mask_lane);
-        if constexpr ((V >> kZCapsule) & 1) list_grid<kZCapsule>(E, D.n_zcapsule, D.off_zcapsule, D.wbase_zcapsule, cw, x, y, z, r, rsq, ext, hit, mask_lane);
-        if constexpr ((V >> kCuboid) & 1) list_grid<kCuboid>(E, D.n_cuboid, D.off_cuboid, D.wbase_cuboid, cw, x, y, z, r, rsq, ext, hit, mask_lane);
-        if constexpr ((V >> kZCuboid) & 1) list_grid<kZCuboid>(E, D.n_zcuboid, D.off_zcuboid, D.wbase_zcuboid, cw, x, y, z, r, rsq, ext, hit, mask_lane);
+        if constexpr ((V >> kSphere) & 1) list_grid<kSphere>(E, VMV_HN(kSphere, sphere), VMV_HOFF(kSphere, sphere), VMV_HWB(kSphere, sphere), cw, x, y, z, r, rsq, ext, hit, mask_lane);
+        if constexpr ((V >> kCapsule) & 1) list_grid<kCapsule>(E, VMV_HN(kCapsule, capsule), VMV_HOFF(kCapsule, capsule), VMV_HWB(kCapsule, capsule), cw, x, y, z, r, rsq, ext, hit, mask_lane);
+        if constexpr ((V >> kZCapsule) & 1) list_grid<kZCapsule>(E, VMV_HN(kZCapsule, zcapsule), VMV_HOFF(kZCapsule, zcapsule), VMV_HWB(kZCapsule, zcapsule), cw, x, y, z, r, rsq, ext, hit, mask_lane);
+        if constexpr ((V >> kCuboid) & 1) list_grid<kCuboid>(E, VMV_HN(kCuboid, cuboid), VMV_HOFF(kCuboid, cuboid), VMV_HWB(kCuboid, cuboid), cw, x, y, z, r, rsq, ext, hit, mask_lane);
+        if constexpr ((V >> kZCuboid) & 1) list_grid<kZCuboid>(E, VMV_HN(kZCuboid, zcuboid), VMV_HOFF(kZCuboid, zcuboid), VMV_HWB(kZCuboid, zcuboid), cw, x, y, z, r, rsq, ext, hit, mask_lane);
         hit = hit && active;
         if constexpr (((V >> 5) & 1) == 0) return hit;
         for (uint32_t hi = 0; hi < D.n_heightfield; ++hi)  // validity.hh:131-137
@@ -1274,19 +1321,20 @@ namespace vmv
         lds_u32 *list = (lds_u32 *) uniform((lds_cptr) scratch_);
         lds_u32 *mask_lane = list + 2 * kWave + 4 + lane;
         if (VMV_ABLATE_ENV == 2) return slab[0] > 1e30f;  // measurement aid: FK only (keeps the FK results alive)
+        const ListHdr H = load_list_hdr<V>(E.dev);
         bool own;
         if (E.dev->masked_fine && E.dev->grid[0].cells != nullptr)
-            own = env_hit_grid<G, V, !PRE>(E, (uint32_t) uniform(grid_class_), slab[0], slab[kRow], slab[2 * kRow],
+            own = env_hit_grid<G, V, !PRE>(E, H, (uint32_t) uniform(grid_class_), slab[0], slab[kRow], slab[2 * kRow],
                                   Tab::radius(uniform(radius_index_)), active, mask_lane);
         else if (E.dev->masked_fine)
         {
 #pragma unroll
             for (int w = 0; w < kMaskWords; ++w) mask_lane[w * kWave] = 0u;
-            own = env_hit<G, 1, V, !PRE>(E, slab[0], slab[kRow], slab[2 * kRow], Tab::radius(uniform(radius_index_)), active,
+            own = env_hit<G, 1, V, !PRE>(E, H, slab[0], slab[kRow], slab[2 * kRow], Tab::radius(uniform(radius_index_)), active,
                                 mask_lane);
         }
         else
-            own = env_hit<G, 0, V, !PRE>(E, slab[0], slab[kRow], slab[2 * kRow], Tab::radius(uniform(radius_index_)), active,
+            own = env_hit<G, 0, V, !PRE>(E, H, slab[0], slab[kRow], slab[2 * kRow], Tab::radius(uniform(radius_index_)), active,
                                 nullptr);
         if constexpr (PRE) own = own || (pre && active);
         const bool gate = group_any<G>(own);
@@ -1326,6 +1374,9 @@ namespace vmv
         const int k = (int) uniform(list[2 * kWave]);
         if (k == 0) return;
         const bool masked = E.dev->masked_fine != 0u && uniform(full_) == 0;
+        // (the list header is NOT hoisted out of the rounds here: fetched once up front, pinned or not, it takes env_fine's
+        // body from 62 to the limit of 96 SGPRs and into SGPR spills through a VGPR it first has to save to scratch, once
+        // per call; the gate, which has SGPRs to spare, works from the pinned copy)
         lds_cptr wave_slab = uniform(slab - lane);
         const int items = k * n_fine;
         const float inv_k = 1.0f / (float) k;
@@ -1374,6 +1425,9 @@ namespace vmv
     // words [64], compacted items [8 * 64]
     constexpr int kSelfScratchWords = 3 * kWave + 4 + 8 * kWave;
 
+#undef VMV_HN
+#undef VMV_HOFF
+#undef VMV_HWB
     __device__ __forceinline__ bool env_flag(lds_ptr scratch)
     {
         return ((lds_u32 *) scratch)[kWave + __lane_id()] != 0u;
