@@ -317,7 +317,7 @@ def self_tables(m, N=SELF_TABLE_N):
 
 
 SELF_DEAL_MAX_A = 40  # A-side spheres kept in registers for the re-dealt self-collision form
-ENV_CHUNK = {"panda": 5, "ur5": 5}   # fine spheres per slab chunk in the environment kernels (default CHUNK); a smaller slab
+ENV_CHUNK = {"panda": 6, "ur5": 6}   # fine spheres per slab chunk in the environment kernels (default CHUNK); a smaller slab
 ENV_BLOCKS = {"panda": 5, "ur5": 5, "baxter": 5}  # (baxter: 0.331 -> 0.307 ms per 1M configs at 5)  # ... lets five workgroups (20 waves) share a CU's LDS where the registers allow it
 # workgroups per CU the self kernel is compiled for (512 / blocks VGPRs per lane) and fine spheres per slab chunk of the
 # self-collision kernels.  Panda, measured (blocks x chunk, self kernel ms per 1M configs): 3x8 0.145, 4x8 0.133,
@@ -339,7 +339,7 @@ SELF_DENSE_MIN_A = 3    # ... and whose A side is at least this large use the pr
 SPARSE_BATCH = 8        # sparse groups merged per item list (the list holds SPARSE_BATCH * 64 entries = CHUNK * 64)
 SELF_MARGIN = 1e-4      # metres; enclosure of fine spheres by bounding spheres is asserted to 2e-6 by tools/robot_trace.py
 LAZY_FINE_FK = os.environ.get("VMV_LAZY_FINE_FK", "1") == "1"  # see emit_env_link
-DEFAULT_CHUNK = 8  # fine spheres staged in the LDS slab at a time (slab = 1 bounding + CHUNK fine spheres per wave)
+DEFAULT_CHUNK = 8  # fine spheres staged in the LDS slab at a time
 assert SPARSE_BATCH <= 8 and DEFAULT_CHUNK <= 8  # vmv::kSelfScratchWords holds 8 * 64 list entries
 
 
@@ -412,7 +412,7 @@ def emit_robot(m):
         radii_tab += [radii[g["bound"]]] + [radii[s] for s in g["fine"]]
     max_group = max(len(g["fine"]) for g in m["env_groups"])
     env_chunk = ENV_CHUNK.get(n, DEFAULT_CHUNK)
-    slab_spheres = 1 + min(env_chunk, max_group)
+    slab_spheres = min(env_chunk, max_group)  # rows of the environment slab: one chunk of fine spheres (the bounding sphere travels in registers)
     self_slab_spheres = 1 + min(CHUNK, max_group)
 
     L.append(f"namespace {n}")
@@ -420,7 +420,7 @@ def emit_robot(m):
     L.append(f"    constexpr int kDim = {dim};")
     L.append(f"    constexpr int kNSpheres = {m['n_spheres']};")
     L.append(f"    constexpr int kResolution = {m['resolution']};")
-    L.append(f"    constexpr int kSlabSpheres = {slab_spheres};  // environment kernels: bounding sphere + one chunk of fine spheres")
+    L.append(f"    constexpr int kSlabSpheres = {slab_spheres};  // environment kernels: one chunk of fine spheres")
     L.append(f"    constexpr int kSelfSlabSpheres = {self_slab_spheres};  // self-collision kernels: one chunk of B spheres")
     L.append(f"    constexpr int kNRadii = {len(radii_tab)};")
     L.append(f"    __constant__ float kRadii[{len(radii_tab)}] = {{" + ", ".join(flit(v) for v in radii_tab) + "};")
@@ -474,10 +474,11 @@ def emit_robot(m):
             for k in range(3):
                 em.lines.append(f"{indent}slab[{3 * slot + k} * vmv::kRow] = {em.coord(s, k)};")
 
-        stage(0, g["bound"], "        ")
+        # (the bounding sphere goes to the gate in registers: no slab row, no LDS round trip between caller and gate)
+        bc = ", ".join(em.coord(g["bound"], k) for k in range(3))
         if not lazy:
             for si, s in enumerate(chunks[0]):
-                stage(1 + si, s, "        ")
+                stage(si, s, "        ")
         if pair_with is not None:
             # paired variant: the point-cloud queries of this link's bounding sphere and of the next link's, together
             # (vmv::capt_gate_pair); bit 0 = this link, bit 1 = the next one (consumed by its own gate below)
@@ -489,23 +490,24 @@ def emit_robot(m):
                             f"{radii_off[pair_with]}, !bad);  // {ln} + {pair_with}")
         em.lines.append("        {")
         if pre is not None:
-            em.lines.append(f"            const bool gate = vmv::env_gate<G, Tab, V, true>(E, slab, scratch, {radii_off[ln]}, "
+            em.lines.append(f"            const bool gate = vmv::env_gate<G, Tab, V, true>(E, {bc}, scratch, {radii_off[ln]}, "
                             f"{link_class[ln]}, !bad, ({pre[0]} & {pre[1]}u) != 0u);")
         else:
-            em.lines.append(f"            const bool gate = vmv::env_gate<G, Tab, V>(E, slab, scratch, {radii_off[ln]}, {link_class[ln]}, !bad);")
+            em.lines.append(f"            const bool gate = vmv::env_gate<G, Tab, V>(E, {bc}, scratch, {radii_off[ln]}, {link_class[ln]}, !bad);")
+        em.lines.append("            const int n_gate = __popcll(__ballot(gate));  // passing lanes (whole rakes), wave-uniform")
         em.lines.append("            if (VMV_ABLATE_ENV >= 1) bad |= gate;  // measurement aid: no fine phase (wrong answers)")
-        em.lines.append("            else if (vmv::wave_any(gate))")
+        em.lines.append("            else if (n_gate != 0)")
         em.lines.append("            {")
         if lazy:
             em.emit_ops(private, indent="                ")
             for si, s in enumerate(chunks[0]):
-                stage(1 + si, s, "                ")
+                stage(si, s, "                ")
         done = 0
         for ci, ch in enumerate(chunks):
             if ci > 0:
                 for si, s in enumerate(ch):
-                    stage(1 + si, s, "                ")
-            em.lines.append(f"                vmv::env_fine<G, Tab, V>(E, slab, scratch, {len(ch)}, {radii_off[ln] + 1 + done});")
+                    stage(si, s, "                ")
+            em.lines.append(f"                vmv::env_fine<G, Tab, V>(E, slab, scratch, {len(ch)}, {radii_off[ln] + 1 + done}, 0, n_gate);")
             done += len(ch)
         em.lines.append("                bad |= gate && vmv::group_any<G>(vmv::env_flag(scratch));")
         em.lines.append("            }")
@@ -930,7 +932,7 @@ def emit_robot(m):
     L.append("            z = (((Rn[2][0] * sx) + (Rn[2][1] * sy)) + (Rn[2][2] * sz)) + tn[2];")
     L.append("        };")
     L.append("        // attachment vs. environment: chunks of posed spheres through the slab, re-dealt like a link's fine spheres")
-    att_chunk = slab_spheres - 1  # the slab holds 1 + min(CHUNK, largest link) spheres
+    att_chunk = slab_spheres  # the slab holds min(CHUNK, largest link) spheres
     L.append(f"        for (unsigned base = 0; base < na; base += {att_chunk}u)")
     L.append("        {")
     L.append(f"            const unsigned cnt = (na - base < {att_chunk}u) ? na - base : {att_chunk}u;")
@@ -938,9 +940,9 @@ def emit_robot(m):
     L.append("            {")
     L.append("                float x, y, z, r;")
     L.append("                posed(base + s, x, y, z, r);")
-    L.append("                slab[(3 * (s + 1) + 0) * vmv::kRow] = x;")
-    L.append("                slab[(3 * (s + 1) + 1) * vmv::kRow] = y;")
-    L.append("                slab[(3 * (s + 1) + 2) * vmv::kRow] = z;")
+    L.append("                slab[(3 * s + 0) * vmv::kRow] = x;")
+    L.append("                slab[(3 * s + 1) * vmv::kRow] = y;")
+    L.append("                slab[(3 * s + 2) * vmv::kRow] = z;")
     L.append("            }")
     L.append("            const bool act = vmv::env_list_active<G>(scratch, !bad);")
     L.append("            if (vmv::wave_any(act))")

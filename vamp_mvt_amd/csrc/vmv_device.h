@@ -1270,9 +1270,9 @@ namespace vmv
 
     // One link's environment group (robots/panda.hh:5629-6010): `if (hit(bounding)) { any fine sphere hits }`.
     //
-    // The link's sphere centres are staged in this wave's LDS slab, slab[(3*s + k) * 64 + lane] (s = 0 is the
-    // bounding sphere; `slab` already points at this lane's column), in chunks of at most kChunk fine spheres
-    // so that the slab stays small enough for 4+ waves per SIMD.
+    // The link's FINE sphere centres are staged in this wave's LDS slab, slab[(3*s + k) * 65 + lane] (`slab` already
+    // points at this lane's column), in chunks of at most kChunk spheres so that the slab stays small enough for 4+
+    // waves per SIMD; the bounding sphere goes to the gate in registers.
     //   env_gate   every lane tests its own bounding sphere (lane = configuration); the lanes of the rakes whose
     //              gate fired are listed in LDS.
     //   env_fine   for one staged chunk: only rakes whose gate fired matter, typically a few of the 64 lanes.
@@ -1313,29 +1313,30 @@ namespace vmv
 
     template <int G, typename Tab, int V = kEnvFull, bool PRE = false>
     __device__ __noinline__ bool
-    env_gate(const EnvView E_, lds_cptr slab, lds_ptr scratch_, const int radius_index_, const int grid_class_,
-             const bool active, const bool pre = false /* PRE: this lane's bounding sphere collides with a point cloud */)
+    env_gate(const EnvView E_, const float bx, const float by, const float bz, lds_ptr scratch_, const int radius_index_,
+             const int grid_class_, const bool active,
+             const bool pre = false /* PRE: this lane's bounding sphere collides with a point cloud */)
     {
+        // (bx, by, bz: this lane's bounding-sphere centre, in registers — it used to travel through the slab's row 0:
+        // three LDS stores in the caller, a load and a wait here, per gate)
         const uint32_t lane = __lane_id();
         const EnvView E{uniform(E_.dev), uniform(E_.lds), uniform(E_.capt0_planes_in_lds), uniform(E_.radii)};
         lds_u32 *list = (lds_u32 *) uniform((lds_cptr) scratch_);
         lds_u32 *mask_lane = list + 2 * kWave + 4 + lane;
-        if (VMV_ABLATE_ENV == 2) return slab[0] > 1e30f;  // measurement aid: FK only (keeps the FK results alive)
+        if (VMV_ABLATE_ENV == 2) return bx + by + bz > 1e30f;  // measurement aid: FK only (keeps the FK results alive)
         const ListHdr H = load_list_hdr<V>(E.dev);
         bool own;
         if (E.dev->masked_fine && E.dev->grid[0].cells != nullptr)
-            own = env_hit_grid<G, V, !PRE>(E, H, (uint32_t) uniform(grid_class_), slab[0], slab[kRow], slab[2 * kRow],
+            own = env_hit_grid<G, V, !PRE>(E, H, (uint32_t) uniform(grid_class_), bx, by, bz,
                                   Tab::radius(uniform(radius_index_)), active, mask_lane);
         else if (E.dev->masked_fine)
         {
 #pragma unroll
             for (int w = 0; w < kMaskWords; ++w) mask_lane[w * kWave] = 0u;
-            own = env_hit<G, 1, V, !PRE>(E, H, slab[0], slab[kRow], slab[2 * kRow], Tab::radius(uniform(radius_index_)), active,
-                                mask_lane);
+            own = env_hit<G, 1, V, !PRE>(E, H, bx, by, bz, Tab::radius(uniform(radius_index_)), active, mask_lane);
         }
         else
-            own = env_hit<G, 0, V, !PRE>(E, H, slab[0], slab[kRow], slab[2 * kRow], Tab::radius(uniform(radius_index_)), active,
-                                nullptr);
+            own = env_hit<G, 0, V, !PRE>(E, H, bx, by, bz, Tab::radius(uniform(radius_index_)), active, nullptr);
         if constexpr (PRE) own = own || (pre && active);
         const bool gate = group_any<G>(own);
         const uint64_t mask = __ballot(gate);
@@ -1364,14 +1365,16 @@ namespace vmv
     template <int G, typename Tab, int V = kEnvFull>
     __device__ __noinline__ void
     env_fine(const EnvView E_, lds_cptr slab, lds_ptr scratch_, const int n_fine_, const int radii_offset_,
-             const int full_ = 0 /* 1: no candidate words (spheres without a bounding-sphere pass: attachments) */)
+             const int full_ = 0 /* 1: no candidate words (spheres without a bounding-sphere pass: attachments) */,
+             const int k_ = -1 /* listed lanes, if the caller knows (else read from the list's header word in LDS) */)
     {
         const uint32_t lane = __lane_id();
         const EnvView E{uniform(E_.dev), uniform(E_.lds), uniform(E_.capt0_planes_in_lds), uniform(E_.radii)};
         lds_u32 *list = (lds_u32 *) uniform((lds_cptr) scratch_);
         lds_u32 *flags = list + kWave;
         const int n_fine = uniform(n_fine_), radii_offset = uniform(radii_offset_);
-        const int k = (int) uniform(list[2 * kWave]);
+        const int k_known = uniform(k_);
+        const int k = k_known >= 0 ? k_known : (int) uniform(list[2 * kWave]);
         if (k == 0) return;
         const bool masked = E.dev->masked_fine != 0u && uniform(full_) == 0;
         // (the list header is NOT hoisted out of the rounds here: fetched once up front, pinned or not, it takes env_fine's
@@ -1389,7 +1392,7 @@ namespace vmv
             s = act ? s : 0;
             const int j = act ? (i - s * k) : 0;
             const uint32_t src = list[j];
-            lds_cptr p = wave_slab + 3 * (s + 1) * kRow + src;
+            lds_cptr p = wave_slab + 3 * s * kRow + src;  // (row s of the slab: fine sphere s of the staged chunk)
             bool hit;
             if (masked)
                 hit = env_hit<G, 2, V>(E, p[0], p[kRow], p[2 * kRow], E.radii[radii_offset + s], act,
