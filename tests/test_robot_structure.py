@@ -42,3 +42,36 @@ def test_oracle_and_library_tables_equal_the_references(oracle, vamp, golden_dir
     orid = oracle.robot(name)
     assert oracle.n_spheres(orid) == ref["n_spheres"] and oracle.n_total_spheres(orid) == ref["n_total_spheres"]
     assert oracle.dimension(orid) == ref["dimension"] and oracle.resolution(orid) == ref["resolution"]
+
+
+@pytest.mark.parametrize("name", ["panda", "ur5", "fetch", "baxter"])
+def test_merged_gates_enclose_their_fine_spheres(oracle, name):
+    """The primitive-only kernel variants gate several links at once (tools/gen_hip.py: merged_groups): one sphere,
+    centred at one member's bounding centre, for all their fine spheres.  Their pruning is exact only if that sphere
+    ENCLOSES every fine sphere of the group in every configuration — checked here on the oracle's fp32 FK (the arithmetic
+    the kernels run), inside and far outside the joint bounds, to 2e-6 m (the gate's candidate margin is 1e-4 m)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import gen_code
+    import gen_hip
+
+    m = gen_code.load(name)
+    groups = gen_hip.merged_groups(m)
+    merged = [g for g in groups if len(g["members"]) > 1]
+    assert merged, "no rigid cluster found"
+    # every fine sphere of the robot sits in exactly one gate, in the reference's order inside its link
+    assert sorted(s for g in groups for s in g["fine"]) == list(range(m["n_spheres"]))
+    assert [ln for g in groups for ln in g["members"]] == m["links"]
+    rid = oracle.robot(name)
+    lo, span = oracle.bounds(rid)
+    rng = np.random.default_rng(7)
+    q = (lo + span * rng.random((1500, len(lo)), dtype=np.float32)).astype(np.float32)
+    q[::3] = (q[::3] * np.float32(2.7)).astype(np.float32)
+    worst = -1.0
+    for cfg in q:
+        s = oracle.fk_all(rid, cfg).astype(np.float64)
+        for g in merged:
+            c = s[g["bound"], :3]
+            reach = np.linalg.norm(s[g["fine"], :3] - c, axis=1) + s[g["fine"], 3]
+            worst = max(worst, float(reach.max() - g["radius"]))
+    assert worst <= 2e-6, worst

@@ -317,7 +317,7 @@ def self_tables(m, N=SELF_TABLE_N):
 
 
 SELF_DEAL_MAX_A = 40  # A-side spheres kept in registers for the re-dealt self-collision form
-ENV_CHUNK = {"panda": 6, "ur5": 6}   # fine spheres per slab chunk in the environment kernels (default CHUNK); a smaller slab
+ENV_CHUNK = {"panda": 6, "ur5": 6, "baxter": 5}   # fine spheres per slab chunk in the environment kernels (default CHUNK); a smaller slab
 ENV_BLOCKS = {"panda": 5, "ur5": 5, "baxter": 5}  # (baxter: 0.331 -> 0.307 ms per 1M configs at 5)  # ... lets five workgroups (20 waves) share a CU's LDS where the registers allow it
 # workgroups per CU the self kernel is compiled for (512 / blocks VGPRs per lane) and fine spheres per slab chunk of the
 # self-collision kernels.  Panda, measured (blocks x chunk, self kernel ms per 1M configs): 3x8 0.145, 4x8 0.133,
@@ -346,10 +346,82 @@ assert SPARSE_BATCH <= 8 and DEFAULT_CHUNK <= 8  # vmv::kSelfScratchWords holds 
 GRID_CLASSES = 4  # vmv::kGridClasses
 
 
+MERGE_RIGID_LINKS = os.environ.get("VMV_NO_MERGED_GROUPS") is None  # (A/B knob at generation time)
+# distances inside a rigid cluster still vary by a few 1e-9 m over the configurations (the tape's fixed-joint rotations
+# are 15-digit constants, not exactly orthonormal); anything a joint moves varies by millimetres and more
+RIGID_TOL = 1e-7
+MERGED_GATE_MAX = 0.13  # metres: links join a common gate while it stays below this (or 1.3 x the largest member's)
+_MERGED_CACHE = {}
+
+
+def merged_groups(m):
+    """Environment groups of the PRIMITIVE-ONLY kernel variants: consecutive links whose fine spheres keep a constant
+    distance to one bounding centre (links hanging on the same moving joint: a gripper's fingers and pads, a wrist's
+    flange) share ONE gate.  For environments made of primitives the reference's answer is the OR over the fine spheres
+    (a flat evaluation reproduces fkcc on 1,000,000 / 1,000,000 configurations) and the bounding-sphere
+    gate only decides which of them are tested, so any sphere that encloses a group's fine spheres is a valid gate;
+    the variant that serves point clouds keeps the reference's groups (its answers depend on them).
+    -> list, in chain order, of dict(link=name, members=[links], bound=sphere id whose CENTRE is the gate's centre,
+    fine=[sphere ids], radius=gate radius)."""
+    if m["name"] in _MERGED_CACHE:
+        return _MERGED_CACHE[m["name"]]
+    env_by_link = {g["link"]: g for g in m["env_groups"]}
+    static = set(static_links(m))
+    rng = np.random.default_rng(12345)
+    lo, sp = np.array(m["lower"]), np.array(m["span"])
+    q = lo + sp * rng.random((96, m["dimension"]))
+    q[:32] *= 2.5  # far outside the bounds too: the distances must not depend on the configuration at all
+    C = eval_tape(m, q)  # float64 centres [96][n_total][3]
+    R = np.array(m["radii"], np.float64)
+
+    def reach(anchor, spheres):
+        """(largest distance + radius of `spheres` from the centre of sphere `anchor`, its spread over the configurations)"""
+        d = np.linalg.norm(C[:, spheres, :] - C[:, [anchor], :], axis=2) + R[spheres][None, :]
+        return float(d.max()), float((d.max(axis=0) - d.min(axis=0)).max())
+
+    out, cur = [], None
+    for ln in m["links"]:
+        g = env_by_link[ln]
+        if ln in static or not MERGE_RIGID_LINKS:
+            cur = None
+            out.append(dict(link=ln, members=[ln], bound=g["bound"], fine=list(g["fine"]), radius=m["radii"][g["bound"]]))
+            continue
+        if cur is not None and reach(cur["bound"], g["fine"])[1] < RIGID_TOL:
+            # joining is worth it while the common gate stays small: a gate the size of a torso fires for every
+            # configuration and hands every primitive near it to every fine sphere of the group
+            members, fine = cur["members"] + [ln], cur["fine"] + g["fine"]
+            cands = [reach(env_by_link[x]["bound"], fine) for x in members]
+            far = min(f for f, spread in cands if spread < RIGID_TOL)
+            biggest = max(m["radii"][env_by_link[x]["bound"]] for x in members)
+            if far <= max(MERGED_GATE_MAX, 1.3 * biggest):
+                cur["members"], cur["fine"] = members, fine
+                continue
+        cur = dict(link=ln, members=[ln], bound=g["bound"], fine=list(g["fine"]), radius=m["radii"][g["bound"]])
+        out.append(cur)
+    for grp in out:
+        if len(grp["members"]) == 1:
+            continue
+        # the member whose bounding centre gives the smallest gate (every candidate re-checked for constancy)
+        best = None
+        for ln in grp["members"]:
+            b = env_by_link[ln]["bound"]
+            far, spread = reach(b, grp["fine"])
+            if spread < RIGID_TOL and (best is None or far < best[0]):
+                best = (far, b)
+        far, b = best
+        # + 5e-6 m: fp32 FK moves centres by ~1e-7 m; the candidate margin of the gate (1e-4 m) is counted from here
+        grp["bound"], grp["radius"] = b, float(np.nextafter(np.float32(far + 5e-6), np.float32(np.inf)))
+        grp["link"] = "+".join(grp["members"])
+    _MERGED_CACHE[m["name"]] = out
+    return out
+
+
 def grid_classes(m):
     """Split the links into GRID_CLASSES classes by bounding radius (contiguous in sorted order), minimising the summed
-    candidate volume (R_class + typical primitive size + cell)^3 over the links.  -> (class radii, {link: class})"""
+    candidate volume (R_class + typical primitive size + cell)^3 over the links.  -> (class radii, {link: class}).
+    The gates of the merged groups (merged_groups) take part under their own names, with their own radii."""
     links = [(m["radii"][g["bound"]], g["link"]) for g in m["env_groups"]]
+    links += [(grp["radius"], grp["link"]) for grp in merged_groups(m) if len(grp["members"]) > 1]
     links.sort()
     r = [x[0] for x in links]
     n = len(r)
@@ -410,9 +482,20 @@ def emit_robot(m):
         g = env_by_link[ln]
         radii_off[ln] = len(radii_tab)
         radii_tab += [radii[g["bound"]]] + [radii[s] for s in g["fine"]]
-    max_group = max(len(g["fine"]) for g in m["env_groups"])
+    # the merged gates of the primitive-only variants (merged_groups): their own radius, then their fine spheres' radii
+    prim_order = []
+    merged_radius = {}
+    for grp in merged_groups(m):
+        prim_order.append(grp["link"])
+        if len(grp["members"]) > 1:
+            env_by_link[grp["link"]] = dict(link=grp["link"], bound=grp["bound"], fine=grp["fine"])
+            merged_radius[grp["link"]] = grp["radius"]
+            radii_off[grp["link"]] = len(radii_tab)
+            radii_tab += [grp["radius"]] + [radii[s] for s in grp["fine"]]
+    max_group = max(len(g["fine"]) for g in m["env_groups"])  # largest link (the self-collision kernels stage links)
+    max_env_group = max([max_group] + [len(grp["fine"]) for grp in merged_groups(m)])  # largest gate of any variant
     env_chunk = ENV_CHUNK.get(n, DEFAULT_CHUNK)
-    slab_spheres = min(env_chunk, max_group)  # rows of the environment slab: one chunk of fine spheres (the bounding sphere travels in registers)
+    slab_spheres = min(env_chunk, max_env_group)  # rows of the environment slab: one chunk of fine spheres (the bounding sphere travels in registers)
     self_slab_spheres = 1 + min(CHUNK, max_group)
 
     L.append(f"namespace {n}")
@@ -435,33 +518,35 @@ def emit_robot(m):
     static = set(static_links(m))
     reach = link_samples(m)
 
-    def emit_env_link(em, ln, lazy=LAZY_FINE_FK, no_skip=False, pair_with=None, pre=None):
+    def emit_env_link(em, ln, lazy=LAZY_FINE_FK, no_skip=False, pair_with=None, pre=None, order=None):
         """one link of the environment half: FK ops, slab staging, gate, fine chunks (appends to em.lines).
         lazy: the FK ops only this link's fine spheres need, and the staging of its first chunk, are emitted inside
         `if (wave_any(gate))` - links whose bounding sphere never reaches an obstacle (the base links in a shell-shaped
         scene) then cost their chain ops and one cell lookup, nothing else."""
+        order = links if order is None else order  # the groups of this walk, in chain order
         g = env_by_link[ln]
         fine = g["fine"]
         chunks = [fine[i:i + env_chunk] for i in range(0, len(fine), env_chunk)]
+        assert all(len(ch) <= slab_spheres for ch in chunks), (ln, slab_spheres)  # a chunk never outgrows the slab
         if ln in static:
             em.lines.append(f"        // ---- {ln}: static, evaluated once per environment (static_env_hit)")
             return
         if ln in os.environ.get("VMV_ABLATE_SKIP_LINKS", "").split(","):  # measurement aid (wrong answers)
             return
         em.lines.append(f"        // ---- {ln}: {len(fine)} spheres")
-        gi_env = m["env_groups"].index(g)
+        gi_env = m["env_groups"].index(g) if g in m["env_groups"] else -1  # (merged gates carry no reach certificate)
         guarded = gi_env in reach and not no_skip
         if guarded:
             # reach certificate (link_samples): for environments no primitive of which this link can ever touch, the
             # launcher sets the link's bit and the wave skips its bounding-sphere FK, cell lookup and gate
-            later_all = [s for other in links[links.index(ln) + 1:] if other not in static
+            later_all = [s for other in order[order.index(ln) + 1:] if other not in static
                          for s in [env_by_link[other]["bound"]] + env_by_link[other]["fine"]]
             em.emit_ops(em.closure([g["bound"]] + fine) & em.closure(later_all))  # what later links need stays outside
             em.lines.append(f"        if (((skip_links >> {gi_env}) & 1ull) == 0ull)")
             em.lines.append("        {")
         private = set()
         if lazy:
-            later = [s for other in links[links.index(ln) + 1:] if other not in static
+            later = [s for other in order[order.index(ln) + 1:] if other not in static
                      for s in [env_by_link[other]["bound"]] + env_by_link[other]["fine"]]
             em.need([g["bound"]])
             fine_ops = em.closure(fine)
@@ -499,12 +584,16 @@ def emit_robot(m):
         em.lines.append("            else if (n_gate != 0)")
         em.lines.append("            {")
         if lazy:
-            em.emit_ops(private, indent="                ")
+            # (chunk by chunk: the FK of a later chunk's spheres is emitted right before that chunk is staged, so the
+            # coordinates of a 27-sphere group are never all live across the fine calls)
+            em.emit_ops(private & em.closure(chunks[0]), indent="                ")
             for si, s in enumerate(chunks[0]):
                 stage(si, s, "                ")
         done = 0
         for ci, ch in enumerate(chunks):
             if ci > 0:
+                if lazy:
+                    em.emit_ops(private & em.closure(ch), indent="                ")
                 for si, s in enumerate(ch):
                     stage(si, s, "                ")
             em.lines.append(f"                vmv::env_fine<G, Tab, V>(E, slab, scratch, {len(ch)}, {radii_off[ln] + 1 + done}, 0, n_gate);")
@@ -534,8 +623,12 @@ def emit_robot(m):
         em = Emitter(m)
         skipped = os.environ.get("VMV_ABLATE_SKIP_LINKS", "").split(",")
         movable = [ln for ln in links if ln not in static and ln not in skipped]
-        for ln in links:
-            if not paired or ln not in movable:
+        if not paired:
+            # primitive-only variants: rigidly connected links share one gate (merged_groups)
+            for ln in prim_order:
+                emit_env_link(em, ln, order=prim_order)
+        for ln in (links if paired else []):
+            if ln not in movable:
                 emit_env_link(em, ln)
                 continue
             # links (0, 1), (2, 3), ... of the chain share one pair of point-cloud queries; reach certificates never
@@ -1107,7 +1200,7 @@ def main(models):
         sp = ", ".join(flit(v) for v in m["span"] + [0.0] * (16 - m["dimension"]))
         ds = ", ".join(flit(v) for v in m["descale"] + [0.0] * (16 - m["dimension"]))
         jn = ", ".join('"%s"' % j for j in m["joint_names"])
-        max_bound = max(m["radii"][m["n_spheres"]:])
+        max_bound = max(m["radii"][m["n_spheres"]:] + [grp["radius"] for grp in merged_groups(m)])
         gr = ", ".join(flit(v) for v in grid_classes(m)[0])
         host.append(f'    {{"{m["name"]}", {m["dimension"]}, {m["n_spheres"]}, {m["resolution"]}, '
                     f'{flit(m["min_radius"])}, {flit(m["max_radius"])}, {flit(max_bound)}, {{{gr}}}, {{{lo}}}, {{{sp}}}, {{{ds}}}, '

@@ -614,6 +614,7 @@ extern "C"
                     const double k = vv * (double) c.p[7];
                     well_formed = well_formed && std::isfinite(k) && std::fabs(k - 1.0) <= 1e-3;
                 }
+            D.ill_formed = well_formed ? 0u : 1u;
             if (!well_formed) D.masked_fine = 0u;
         }
         while (block.size() % 4) block.push_back(0.f);

@@ -265,6 +265,11 @@ namespace vmv
         // "some static link of the robot (its spheres do not depend on the configuration) collides with this
         // environment": evaluated once per (environment, robot) by static_links_kernel with the same device functions
         uint32_t static_hit;
+        // an ill-formed cuboid / capsule (axes not orthonormal, rdv != 1 / |v|^2): its "distance" is not 1-Lipschitz, so a
+        // bounding sphere can test clear while a sphere inside it tests colliding — the reference's answer then depends on
+        // which spheres ITS gates guard.  Such environments run the variant that keeps the reference's groups and the
+        // full sorted loops (the launchers pick it), never the merged gates of the primitive-only variants.
+        uint32_t ill_formed;
         unsigned long long link_skip;  // bit g: environment group g can never touch this environment (reach certificates)
         uint32_t n_capt;
         uint32_t capt0_n_tests;  // size of capt[0].tests (candidate for LDS staging behind the primitive block)
