@@ -317,8 +317,11 @@ def self_tables(m, N=SELF_TABLE_N):
 
 
 SELF_DEAL_MAX_A = 40  # A-side spheres kept in registers for the re-dealt self-collision form
-ENV_CHUNK = {"panda": 6, "ur5": 6, "baxter": 5}   # fine spheres per slab chunk in the environment kernels (default CHUNK); a smaller slab
-ENV_BLOCKS = {"panda": 5, "ur5": 5, "baxter": 5}  # (baxter: 0.331 -> 0.307 ms per 1M configs at 5)  # ... lets five workgroups (20 waves) share a CU's LDS where the registers allow it
+ENV_CHUNK = {"panda": 4, "ur5": 6, "baxter": 5}   # fine spheres per slab chunk in the environment kernels (default CHUNK); a smaller slab
+ENV_BLOCKS = {"panda": 6, "ur5": 5, "baxter": 5}  # (baxter: 0.331 -> 0.307 ms per 1M configs at 5)  # ... lets five or six workgroups (20 - 24 waves) share a CU's LDS where the registers allow it
+# Panda, round 3: with the merged gates and the FK of a group emitted chunk by chunk the three-list kernel needs 81 VGPRs;
+# at six workgroups per CU (80 VGPRs, no spill) and chunks of 4 (23.9 KB of LDS per workgroup) it runs 0.1375 -> 0.1288 ms
+# per 1M configurations.  The same setting costs UR5 1.5 % (and 2.5 % on its edges): it stays at 5 x 6.
 # workgroups per CU the self kernel is compiled for (512 / blocks VGPRs per lane) and fine spheres per slab chunk of the
 # self-collision kernels.  Panda, measured (blocks x chunk, self kernel ms per 1M configs): 3x8 0.145, 4x8 0.133,
 # 4x7 0.127, 4x6 0.126, 4x5 0.132, 4x4 0.140, 5x5 0.210 - with chunks of 8 the fourth workgroup did not fit the LDS.
