@@ -63,6 +63,11 @@ def spec_for(kind, robot="panda", seed=0):
         k = XY_SCALE[robot] if robot == "baxter" else 1.0
         spec.append(("capt", (shell_cloud(2000, seed + 7, 0.6 * k, 1.2 * k), r_min, r_max, POINT_RADIUS)))
         return spec
+    if kind == "clouds":  # two point clouds and nothing else: the kernels' cloud-only variant (vmv_device.h kEnvClouds)
+        r_min, r_max = RADII[robot]
+        k = XY_SCALE[robot] if robot == "baxter" else 1.0
+        return [("capt", (shell_cloud(1500, seed + 9, 0.6 * k, 1.2 * k), r_min, r_max, POINT_RADIUS)),
+                ("capt", (shell_cloud(700, seed + 10, 0.9 * k, 1.5 * k), r_min, r_max, 2 * POINT_RADIUS))]
     if kind == "config3":  # BASELINE config 3: Fetch vs a 10,000-point CAPT cloud (tools/bench_configs.py, same generator)
         return [("capt", (shell_cloud(10000, 3), *RADII[robot], POINT_RADIUS))]
     if kind == "config5":  # BASELINE config 5: Baxter, 32 primitives + a 10,000-point CAPT cloud (tools/bench_configs.py)

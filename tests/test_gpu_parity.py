@@ -12,7 +12,7 @@ from workmix import case_seed, mixed_configs, mixed_edges
 
 pytestmark = pytest.mark.gpu
 ROBOTS = ["panda", "ur5", "fetch", "baxter"]
-KINDS = ["empty", "cage", "shell64", "mixed", "capt", "heightfield", "attach", "attach_free"]
+KINDS = ["empty", "cage", "shell64", "mixed", "capt", "clouds", "heightfield", "attach", "attach_free"]
 
 
 def uniform_configs(oracle, name, n, seed):
@@ -38,7 +38,7 @@ def _non_degenerate(want, n):
 def test_validate_batch_bit_exact(vamp, oracle, name, kind):
     """uniform configurations (whatever their validity) + configurations searched around valid postures (workmix)"""
     env, oenv = make_env(kind, oracle, name)
-    n = 12000 if kind != "capt" else 4000
+    n = 12000 if kind not in ("capt", "clouds") else 4000
     rid, q = uniform_configs(oracle, name, n, seed=case_seed(name, kind, "uniform") % 100000)
     got = getattr(vamp, name).validate_batch(q, env)
     want = oracle.validate_batch(rid, oenv, q, threads=8)
@@ -50,12 +50,12 @@ def test_validate_batch_bit_exact(vamp, oracle, name, kind):
 
 
 @pytest.mark.parametrize("name", ROBOTS)
-@pytest.mark.parametrize("kind", ["empty", "cage", "shell64", "mixed", "capt", "heightfield", "attach", "attach_free"])
+@pytest.mark.parametrize("kind", KINDS)
 def test_validate_motion_batch_bit_exact(vamp, oracle, name, kind):
     """Edges with distinct configurations per rake lane: exercises the 8-lane "any lane" gating.  Starts near valid
     postures, steps of several lengths, every 7th edge zero-length (n = 1, block = start)."""
     env, oenv = make_env(kind, oracle, name)
-    n = 1500 if kind != "capt" else 600
+    n = 1500 if kind not in ("capt", "clouds") else 600
     rid, a, b, want = mixed_edges(oracle, name, oenv, n, case_seed(name, kind, "edges"), zero_every=7)
     _non_degenerate(want, n)
     assert np.array_equal(getattr(vamp, name).validate_motion_batch(a, b, env), want)
@@ -67,7 +67,7 @@ def test_validate_motion_batch_bit_exact(vamp, oracle, name, kind):
 
 
 @pytest.mark.parametrize("name", ROBOTS)
-@pytest.mark.parametrize("kind", ["shell64", "mixed", "capt", "attach", "heightfield"])
+@pytest.mark.parametrize("kind", ["shell64", "mixed", "capt", "clouds", "attach", "heightfield"])
 @pytest.mark.parametrize("mode", [0, 1, 2, 3])
 def test_edge_schedules_are_bit_exact(vamp, oracle, monkeypatch, name, kind, mode):
     """vmv_validate_motion_batch has four schedules (csrc/vmv_robot_tu.inc: launch_validate_motion): 0 = one rake group
@@ -77,7 +77,7 @@ def test_edge_schedules_are_bit_exact(vamp, oracle, monkeypatch, name, kind, mod
     monkeypatch.setenv("VMV_EDGE_TASKS", str(mode))
     env, oenv = make_env(kind, oracle, name)
     mod = getattr(vamp, name)
-    n = 1100 if kind != "capt" else 500
+    n = 1100 if kind not in ("capt", "clouds") else 500
     rid, a, b, want = mixed_edges(oracle, name, oenv, n, case_seed(name, kind, "schedules"), zero_every=5)
     _non_degenerate(want, n)
     assert np.array_equal(mod.validate_motion_batch(a, b, env), want)

@@ -76,6 +76,14 @@ def random_spec(rng, robot):
         sp = [[rng.uniform(-0.1, 0.1), rng.uniform(-0.1, 0.1), rng.uniform(0, 0.3), rng.uniform(0.01, 0.05)]
               for _ in range(int(rng.integers(1, 14)))]
         spec.append(("attach", (tf, np.array(sp, np.float32))))
+    if rng.random() < 0.12:  # point clouds and nothing else (one or two): the kernels' cloud-only variant
+        spec = [e for e in spec if e[0] in ("capt", "attach")]
+        k = 1.6 if robot == "baxter" else 1.0
+        r_min, r_max = RADII[robot]
+        while sum(e[0] == "capt" for e in spec) < (2 if rng.random() < 0.4 else 1):
+            n = int(rng.choice([2, 17, 300, 1000, 4096, 10000]))
+            spec.insert(0, ("capt", (shell_cloud(n, int(rng.integers(1 << 30)), 0.5 * k, 1.3 * k, 0.0, 1.5), r_min, r_max,
+                                     POINT_RADIUS * float(rng.choice([1.0, 2.0])))))
     return spec
 
 

@@ -578,7 +578,10 @@ def emit_robot(m):
                             f"{radii_off[pair_with]}, !bad);  // {ln} + {pair_with}")
         em.lines.append("        {")
         if pre is not None:
-            em.lines.append(f"            const bool gate = vmv::env_gate<G, Tab, V, true>(E, {bc}, scratch, {radii_off[ln]}, "
+            # (V = kEnvClouds: nothing is left for the gate to test, the lanes whose query hit are listed without a call)
+            em.lines.append("            bool gate;")
+            em.lines.append(f"            if constexpr (V == vmv::kEnvClouds) gate = vmv::env_list_active<G>(scratch, ({pre[0]} & {pre[1]}u) != 0u && !bad);")
+            em.lines.append(f"            else gate = vmv::env_gate<G, Tab, V, true>(E, {bc}, scratch, {radii_off[ln]}, "
                             f"{link_class[ln]}, !bad, ({pre[0]} & {pre[1]}u) != 0u);")
         else:
             em.lines.append(f"            const bool gate = vmv::env_gate<G, Tab, V>(E, {bc}, scratch, {radii_off[ln]}, {link_class[ln]}, !bad);")
@@ -612,11 +615,9 @@ def emit_robot(m):
         L.append("    __device__ __forceinline__ bool")
         L.append(f"    {name}(const vmv::EnvView &E, const float (&q)[kDim], vmv::lds_ptr slab, const bool skip)")
         L.append("    {")
-        if paired:
-            L.append("        constexpr int V = vmv::kEnvFull;")
-        else:
+        if not paired:
             L.append("#ifndef VMV_NO_CAPT_PAIR  // (A/B knob, tools/build_variant.py: every gate queries the clouds on its own)")
-            L.append("        if constexpr (V == vmv::kEnvFull) return fkcc_env_paired<G>(E, q, slab, skip);")
+            L.append("        if constexpr (V == vmv::kEnvFull || V == vmv::kEnvClouds) return fkcc_env_paired<G, V>(E, q, slab, skip);")
             L.append("#endif")
         L.append("        bool bad = skip || (E.dev->static_hit != 0u);")
         L.append("        // per-wave scratch words live right behind the sphere slab")
@@ -653,10 +654,10 @@ def emit_robot(m):
     L.append("    // collisions\"): true = some link group of this rake reports a collision.")
     L.append("    // `skip` (rake-uniform): this rake's answer is not needed; it only keeps the lanes converged.")
     L.append("    // fkcc_env_paired: the same walk for the variant that serves environments with point clouds / heightfields")
-    L.append("    // (V = kEnvFull): the CAPT queries of the bounding spheres of two consecutive links are issued together")
+    L.append("    // (V = kEnvFull, kEnvClouds): the CAPT queries of the bounding spheres of two consecutive links are issued together")
     L.append("    // (vmv::capt_gate_pair, two dependent-fetch chains in flight per wave) ahead of the first link's gate; each gate")
     L.append("    // then takes its answer instead of querying.  Same predicates on the same spheres: the OR is unchanged.")
-    env_function("fkcc_env_paired", "int G", True)
+    env_function("fkcc_env_paired", "int G, int V", True)
     env_function("fkcc_env", "int G, int V", False)
 
     # ---- static links ------------------------------------------------------------------------------------------

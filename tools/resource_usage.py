@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Developer tool: per-kernel register / spill / occupancy report of the robot translation units
-(hipcc -Rpass-analysis=kernel-resource-usage).  usage: tools/resource_usage.py [robot ...]"""
+(hipcc -Rpass-analysis=kernel-resource-usage).  usage: tools/resource_usage.py [robot ...] [-Dflag ...]"""
 import os
 import re
 import subprocess
@@ -12,9 +12,12 @@ sys.path.insert(0, ROOT)
 from __graft_entry__ import CSRC, HIPFLAGS  # noqa: E402
 
 
+EXTRA = [a for a in sys.argv[1:] if a.startswith("-")]
+
+
 def report(robot):
     src = os.path.join(CSRC, "gen", f"tu_{robot}.hip")
-    r = subprocess.run(["hipcc", *HIPFLAGS, "-Rpass-analysis=kernel-resource-usage", "-c", src, "-o", "/dev/null"],
+    r = subprocess.run(["hipcc", *HIPFLAGS, *EXTRA, "-Rpass-analysis=kernel-resource-usage", "-c", src, "-o", "/dev/null"],
                        capture_output=True, text=True)
     rows, cur = [], None
     for line in r.stderr.splitlines():
@@ -31,7 +34,7 @@ def report(robot):
 
 
 if __name__ == "__main__":
-    robots = sys.argv[1:] or ["panda", "ur5", "fetch", "baxter"]
+    robots = [a for a in sys.argv[1:] if not a.startswith("-")] or ["panda", "ur5", "fetch", "baxter"]
     with ThreadPoolExecutor(4) as ex:
         for robot, rows, rc in ex.map(report, robots):
             print(f"== {robot} (hipcc rc {rc})")

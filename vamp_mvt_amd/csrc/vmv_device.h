@@ -488,7 +488,9 @@ namespace vmv
 #pragma unroll
                 for (int q = 0; q < Q; ++q)
                 {
-                    const g_v4f *b = (const g_v4f *) (bplanes + base + (size_t) path[q] * kCaptPlaneBlock);
+                    // (a query that is out — top box, distance bound, inactive lane — reads block 0 of the group: its
+                    // lanes share one cache line instead of fetching 64 different ones nobody uses)
+                    const g_v4f *b = (const g_v4f *) (bplanes + base + (size_t) (inb[q] ? path[q] : 0u) * kCaptPlaneBlock);
                     pa[q] = b[0], pb[q] = b[1];
                 }
             }
@@ -540,7 +542,7 @@ namespace vmv
             {
                 const float rr = r[q] + r_point;
                 rc_sq[q] = rr * rr;
-                const gw_cptr rec = leaves + (size_t) path[q] * kCaptLeafWords;
+                const gw_cptr rec = leaves + (size_t) (inb[q] ? path[q] : 0u) * kCaptLeafWords;  // (out: leaf 0, as above)
                 const g_v4f *recv = (const g_v4f *) rec;
                 r0[q] = recv[0], r1[q] = recv[1];
                 // the leaf's points are sorted by their distance to the leaf's cell (a lower bound of their distance to
@@ -845,6 +847,9 @@ namespace vmv
     // what an environment-kernel variant compiles in: bits 0..4 = primitive lists (PrimType), bit 5 = heightfields and
     // point clouds
     constexpr int kEnvFull = 63, kEnvPrims = 31, kEnvZOnly = (1 << kSphere) | (1 << kZCapsule) | (1 << kZCuboid);
+    // point clouds and nothing else (no primitive, heightfield or MVT): no list code at all, and the paired walk
+    // lists the lanes whose cloud query hit without a gate call (the launchers pick it: clouds_only)
+    constexpr int kEnvClouds = 32;
     template <int T>
     struct PrimTraits;
     template <> struct PrimTraits<kSphere> { static constexpr int rec = kSphereRec; };
