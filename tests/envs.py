@@ -113,6 +113,33 @@ def spec_for(kind, robot="panda", seed=0):
     raise KeyError(kind)
 
 
+def counted_spec(robot, counts, seed=0):
+    """small primitives scattered through the robot's workspace, exactly counts = (spheres, capsules, z-capsules, cuboids,
+    z-cuboids) of them: list lengths chosen by the caller (the candidate-word layouts of vmv_api.hip: finalize)"""
+    rng = np.random.default_rng(seed)
+    rmin, rmax = SHELL[robot]
+    ns, nc, nzc, nb, nzb = counts
+
+    def pos(zmax=1.4):
+        ang, rad = rng.uniform(0, 2 * np.pi), rng.uniform(0.8 * rmin, 1.1 * rmax)
+        return np.array([rad * np.cos(ang), rad * np.sin(ang), rng.uniform(-0.1, zmax)], np.float32)
+
+    spec = [("sphere", np.array([*pos(), rng.uniform(0.01, 0.06)], np.float32)) for _ in range(ns)]
+    for _ in range(nc):
+        p1 = pos()
+        spec.append(("capsule", capsule(p1, (p1 + rng.uniform(-0.2, 0.2, 3)).astype(np.float32), rng.uniform(0.01, 0.04))))
+    for _ in range(nzc):
+        p1 = pos(1.0)
+        p2 = p1.copy()
+        p2[2] += np.float32(rng.uniform(0.05, 0.3))
+        spec.append(("capsule", capsule(p1, p2, rng.uniform(0.01, 0.04))))
+    for _ in range(nb):
+        spec.append(("cuboid", rot_cuboid(pos(), rng.uniform(-1, 1, 3), rng.uniform(0.01, 0.06, 3))))
+    for _ in range(nzb):
+        spec.append(("cuboid", yaw_cuboid(pos(), rng.uniform(0, 2 * np.pi), rng.uniform(0.01, 0.06, 3))))
+    return spec
+
+
 def build_oracle_env(o, spec):
     e = o.env()
     for kind, p in spec:

@@ -489,6 +489,36 @@ def test_large_primitive_lists_and_capacity(vamp, oracle):
 
 
 @pytest.mark.parametrize("name", ["panda", "baxter"])
+@pytest.mark.parametrize("counts", [
+    (5, 5, 5, 5, 5),        # five short lists: one shared word instead of five
+    (30, 30, 30, 20, 12),   # packs into exactly four words, the last list ends on bit 31 of a shared word
+    (32, 1, 31, 3, 29),     # a list of exactly one word, then lists that fill words to the last bit
+    (20, 20, 5, 40, 10),    # a two-word list between short ones: five words even when shared -> the counted loops
+    (0, 17, 0, 16, 40),     # empty lists take no bits; the two-word list is last
+    (33, 9, 9, 9, 9),       # a two-word list first, four short lists sharing the next word
+])
+def test_shared_candidate_word_layouts(vamp, oracle, name, counts, monkeypatch):
+    """Environments with more lists than candidate words (vmv_device.h kMaskWords = 4): lists of at most 32 primitives share
+    words (EnvDev::wshift_*, vmv_api.hip finalize).  Every layout — shared, word-aligned, too long for either (counted
+    loops) — with the broad-phase grid and without it (VMV_NO_GRID: the counted-loop gate writes the shared words) gives
+    the oracle's booleans, configurations and edges."""
+    from envs import build_oracle_env, build_product_env, counted_spec
+
+    spec = counted_spec(name, counts, seed=case_seed(name, "counted", str(counts)) % 100000)
+    oenv = build_oracle_env(oracle, spec)
+    rid, q, want = mixed_configs(oracle, name, oenv, 6000, case_seed(name, "counted", "configs"))
+    _non_degenerate(want, len(q))
+    rid, a, b, want_e = mixed_edges(oracle, name, oenv, 500, case_seed(name, "counted", "edges"), zero_every=9)
+    for no_grid in (False, True):
+        if no_grid:
+            monkeypatch.setenv("VMV_NO_GRID", "1")
+        env = build_product_env(spec)
+        mod = getattr(vamp, name)
+        assert np.array_equal(mod.validate_batch(q, env), want), f"configurations, no_grid={no_grid}"
+        assert np.array_equal(mod.validate_motion_batch(a, b, env), want_e), f"edges, no_grid={no_grid}"
+
+
+@pytest.mark.parametrize("name", ["panda", "baxter"])
 def test_counted_loop_gate_without_the_grid(vamp, oracle, name, monkeypatch):
     """VMV_NO_GRID=1: the bounding-sphere pass falls back to the counted sorted loops (the path environments take whose
     grid cannot be built); same answers."""

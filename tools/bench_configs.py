@@ -63,8 +63,8 @@ def main():
 
     import vamp_mvt_amd as vamp
     from vamp_mvt_amd.sharding import shard_range, validate_batch_sharded
-    from vamp_mvt_amd.workloads import (POINT_RADIUS, RADII, environment_from_spec, knn_shaped_edges, prm_shaped_edges,
-                                        shell_cloud, shell_spec)
+    from vamp_mvt_amd.workloads import (POINT_RADIUS, RADII, environment_from_spec, knn_shaped_edges, mixed_spec,
+                                        prm_shaped_edges, shell_cloud, shell_spec)
 
     vamp.set_device(local_rank)
 
@@ -117,6 +117,13 @@ def main():
             mod, n, unit = vamp.panda, int((1 << 20) * args.scale), "checks/s"
             env = environment_from_spec(shell_spec(0))
             a, b = uniform(mod, n, 1), None
+        elif cfg.startswith("mixed_"):  # diagnostics: 64 primitives of every kind (the five-list kernel variant)
+            robot = cfg.split("_", 1)[1]
+            mod, n, unit = getattr(vamp, robot), int((1 << 20) * args.scale), "checks/s"
+            env = environment_from_spec(mixed_spec(0, *{"panda": (0.45, 0.95), "ur5": (0.45, 0.95), "fetch": (0.6, 1.2),
+                                                        "baxter": (0.9, 1.6)}[robot]))
+            a, b = uniform(mod, n, 1), None
+            shape = "uniform configurations vs 16 spheres, 16 z-cuboids, 16 rotated cuboids, 8 capsules, 8 z-capsules"
         elif cfg == "config3":
             mod, n, unit = vamp.fetch, int((1 << 20) * args.scale), "checks/s"
             env = environment_from_spec([("capt", (shell_cloud(10000, 3), *RADII["fetch"], POINT_RADIUS))])

@@ -7,7 +7,7 @@ timeout -k 10 400 bash tools/profile.sh r3y_bench > gpurun_out/r3y_prof.log 2>&1
 cp profiles/r03_pmc.json gpurun_out/r3y_r03_pmc.json
 timeout -k 10 200 python bench.py > gpurun_out/r3y_bench.json 2> gpurun_out/r3y_bench.err; echo "bench rc=$?"; python3 -c "
 import json; d=json.load(open('gpurun_out/r3y_bench.json')); r=d['roofline']; print(d['value'], d['ms_per_step'], r['kernel_ms'], r['other_kernels_ms'], r['frac'], r['traffic'], r['pmc_note'], d['two_streams']['value'], json.dumps(d['shard_probe']['shards']))"
-timeout -k 10 400 python tools/bench_configs.py --stats --shard-probe config2 config3 config4 config4_uniform_starts config5 config5_uniform_starts --iters 10 > gpurun_out/r3y_configs.jsonl 2> gpurun_out/r3y_configs.err; echo "configs rc=$?"; python3 -c "
+timeout -k 10 400 python tools/bench_configs.py --stats --shard-probe config2 config3 config4 config4_uniform_starts config5 config5_uniform_starts mixed_panda mixed_ur5 mixed_fetch mixed_baxter --iters 10 > gpurun_out/r3y_configs.jsonl 2> gpurun_out/r3y_configs.err; echo "configs rc=$?"; python3 -c "
 import json
 for l in open('gpurun_out/r3y_configs.jsonl'):
     d=json.loads(l); print(d['config'], d['robot'], round(d['ms'],4), '%.3e'%d['value'], d['unit'], round(d['valid_fraction'],3))"

@@ -578,19 +578,38 @@ extern "C"
         md_array(env->z_capsules, D.off_md_zcapsule);
         md_array(env->cuboids, D.off_md_cuboid);
         md_array(env->z_cuboids, D.off_md_zcuboid);
+        uint32_t total_words = 0;
         {  // candidate words of the fine phase (vmv_device.h, kCandidateMargin): 32 primitives per word, per list
+            uint32_t *const base[5] = {&D.wbase_sphere, &D.wbase_capsule, &D.wbase_zcapsule, &D.wbase_cuboid, &D.wbase_zcuboid};
+            uint32_t *const shift[5] = {&D.wshift_sphere, &D.wshift_capsule, &D.wshift_zcapsule, &D.wshift_cuboid, &D.wshift_zcuboid};
+            const uint32_t count[5] = {D.n_sphere, D.n_capsule, D.n_zcapsule, D.n_cuboid, D.n_zcuboid};
             uint32_t w = 0;
-            auto words = [&](uint32_t n, uint32_t &base)
+            for (int t = 0; t < 5; ++t)
             {
-                base = w;
-                w += (n + 31u) / 32u;
-            };
-            words(D.n_sphere, D.wbase_sphere);
-            words(D.n_capsule, D.wbase_capsule);
-            words(D.n_zcapsule, D.wbase_zcapsule);
-            words(D.n_cuboid, D.wbase_cuboid);
-            words(D.n_zcuboid, D.wbase_zcuboid);
+                *base[t] = w, *shift[t] = 0u;
+                w += (count[t] + 31u) / 32u;
+            }
+            // More lists than words (all five kinds present, say): lists of at most 32 primitives share words — a list
+            // starts at the next free bit when it fits into what is left of the word, else (and always when it is
+            // longer than a word) at bit 0 of the next one.  Not for the environments the three-list kernel variant
+            // serves (well-formed primitives without general cuboids / capsules, nothing else): it reads no shifts.
+            const bool three_lists = env->capsules.empty() && env->cuboids.empty() && env->capts.empty() && env->mvts.empty() &&
+                                     env->heightfields.empty();
+            if (w > (uint32_t) vmv::kMaskWords && !three_lists)
+            {
+                uint32_t pos = 0;  // next free bit
+                for (int t = 0; t < 5; ++t)
+                {
+                    if (count[t] == 0u) continue;
+                    if (count[t] > 32u || (pos % 32u) + count[t] > 32u) pos = (pos + 31u) & ~31u;
+                    *base[t] = pos / 32u, *shift[t] = pos % 32u;
+                    pos += count[t];
+                    if (count[t] > 32u) pos = (pos + 31u) & ~31u;
+                }
+                w = (pos + 31u) / 32u;
+            }
             D.masked_fine = (w <= (uint32_t) vmv::kMaskWords) ? 1u : 0u;
+            total_words = w;
         }
         {
             // The candidate pruning (fine-phase margin, broad-phase grid) assumes 1-Lipschitz primitive distances, which
@@ -734,16 +753,14 @@ extern "C"
         std::vector<vmv::GridPrim> gp;
         if (D.masked_fine)
         {
-            auto add = [&](int type, const float *p, uint32_t wbase, size_t i)
-            { gp.push_back(vmv::GridPrim{type, p, wbase + (uint32_t) (i / 32), (uint32_t) (i % 32)}); };
-            for (size_t i = 0; i < env->spheres.size(); ++i) add(0, &env->spheres[i].x, D.wbase_sphere, i);
-            for (size_t i = 0; i < env->capsules.size(); ++i) add(1, env->capsules[i].p, D.wbase_capsule, i);
-            for (size_t i = 0; i < env->z_capsules.size(); ++i) add(2, env->z_capsules[i].p, D.wbase_zcapsule, i);
-            for (size_t i = 0; i < env->cuboids.size(); ++i) add(3, env->cuboids[i].p, D.wbase_cuboid, i);
-            for (size_t i = 0; i < env->z_cuboids.size(); ++i) add(4, env->z_cuboids[i].p, D.wbase_zcuboid, i);
+            auto add = [&](int type, const float *p, uint32_t wbase, uint32_t shift, size_t i)
+            { gp.push_back(vmv::GridPrim{type, p, wbase + (uint32_t) ((shift + i) / 32), (uint32_t) ((shift + i) % 32)}); };
+            for (size_t i = 0; i < env->spheres.size(); ++i) add(0, &env->spheres[i].x, D.wbase_sphere, D.wshift_sphere, i);
+            for (size_t i = 0; i < env->capsules.size(); ++i) add(1, env->capsules[i].p, D.wbase_capsule, D.wshift_capsule, i);
+            for (size_t i = 0; i < env->z_capsules.size(); ++i) add(2, env->z_capsules[i].p, D.wbase_zcapsule, D.wshift_zcapsule, i);
+            for (size_t i = 0; i < env->cuboids.size(); ++i) add(3, env->cuboids[i].p, D.wbase_cuboid, D.wshift_cuboid, i);
+            for (size_t i = 0; i < env->z_cuboids.size(); ++i) add(4, env->z_cuboids[i].p, D.wbase_zcuboid, D.wshift_zcuboid, i);
         }
-        uint32_t total_words = 0;
-        for (uint32_t n : {D.n_sphere, D.n_capsule, D.n_zcapsule, D.n_cuboid, D.n_zcuboid}) total_words += (n + 31u) / 32u;
         env->base = D_base;
         env->grid_prims = std::move(gp);
         env->grid_words = total_words;

@@ -256,6 +256,11 @@ namespace vmv
         uint32_t off_md_sphere, off_md_capsule, off_md_zcapsule, off_md_cuboid, off_md_zcuboid;  // min_distance arrays
         // candidate words (32 primitives each) per list: first word index, and whether all lists fit kMaskWords
         uint32_t wbase_sphere, wbase_capsule, wbase_zcapsule, wbase_cuboid, wbase_zcuboid, masked_fine;
+        // shared candidate words: a list of at most 32 primitives may start at bit `wshift` of a word whose lower bits
+        // belong to the lists before it (five short lists then take one or two words instead of five; a list longer
+        // than one word always starts at bit 0 of a word of its own).  All 0 unless the word-aligned layout does not
+        // fit kMaskWords; always 0 in environments the three-list variant serves (vmv_api.hip: finalize)
+        uint32_t wshift_sphere, wshift_capsule, wshift_zcapsule, wshift_cuboid, wshift_zcuboid;
         // broad-phase grids of the gate pass (vmv_grid_build.h; robot specific): the robot's links are split into
         // kGridClasses classes by bounding radius (tools/gen_hip.py) and each class has a grid built for its largest
         // radius - a finger (r = 0.024 m) walks far fewer candidates than in a grid sized for the 0.18 m upper arm.
@@ -940,12 +945,16 @@ namespace vmv
     constexpr float kCandidateMargin = 1e-4f;
     constexpr int kMaskWords = 4;  // 32-primitive candidate words per lane kept in LDS (environments with more use full loops)
 
+    // the bits of a candidate word that belong to a list of n primitives: all 32 unless the list is shorter than a word
+    // (only such a list may share its word, EnvDev::wshift_*)
+    __device__ __forceinline__ uint32_t list_word_mask(const uint32_t n) { return n < 32u ? (1u << n) - 1u : 0xffffffffu; }
+
     // One sorted list, full counted loop over the live prefix (records through the scalar cache).  MASK: also
     // write this lane's candidate words for the list to mask_lane[(word) * 64].
     template <int G, int T, bool MASK>
     __device__ __forceinline__ void list_full(const EnvView &E, const uint32_t n, const uint32_t off, const uint32_t off_md,
-                                              const uint32_t wbase, float x, float y, float z, float r, float rsq,
-                                              float ext, float ext_wave, bool &hit, lds_u32 *mask_lane)
+                                              const uint32_t wbase, const uint32_t shift, float x, float y, float z, float r,
+                                              float rsq, float ext, float ext_wave, bool &hit, lds_u32 *mask_lane)
     {
         if (n == 0) return;
         constexpr int REC = PrimTraits<T>::rec;
@@ -978,16 +987,18 @@ namespace vmv
                     const float tau = reach * (2.0f * kCandidateMargin) + kCandidateMargin * kCandidateMargin;
                     m |= (v < tau) ? (1u << (i - b)) : 0u;
                 }
-                mask_lane[(wbase + (b >> 5)) * kWave] = m;
+                // (shift != 0: a one-word list in a shared word, the gate cleared the words before the lists ran)
+                if (shift == 0u) mask_lane[(wbase + (b >> 5)) * kWave] = m;
+                else mask_lane[wbase * kWave] |= m << shift;
             }
         }
     }
 
     // One sorted list, candidates only: mask_src points at the candidate words of the lane this item works for.
-    template <int T>
+    template <int T, bool SHARED>  // SHARED: lists may share candidate words (every variant but the three-list one)
     __device__ __forceinline__ void list_masked(const EnvView &E, const uint32_t n, const uint32_t off, const uint32_t wbase,
-                                                float x, float y, float z, float r, float rsq, float ext, bool active,
-                                                bool &hit, const lds_u32 *mask_src)
+                                                const uint32_t shift, float x, float y, float z, float r, float rsq, float ext,
+                                                bool active, bool &hit, const lds_u32 *mask_src)
     {
         if (n == 0) return;
         constexpr int REC = PrimTraits<T>::rec;
@@ -995,6 +1006,7 @@ namespace vmv
         for (uint32_t w = 0; w < words; ++w)
         {
             uint32_t m = active ? mask_src[(wbase + w) * kWave] : 0u;
+            if constexpr (SHARED) m = (m >> shift) & list_word_mask(n);  // (this list's bits; shift 0, all bits for longer lists)
             // branch-free body: a lane that has run out evaluates record 0 and discards the result (straight-line code
             // instead of an exec-masked region with its copies of every loop-carried value)
             while (wave_any(m != 0u))
@@ -1037,6 +1049,7 @@ namespace vmv
 #define VMV_HN(T, name) ((V == kEnvZOnly) ? H.n[T] : D.n_##name)
 #define VMV_HOFF(T, name) ((V == kEnvZOnly) ? H.off[T] : D.off_##name)
 #define VMV_HWB(T, name) ((V == kEnvZOnly) ? H.wbase[T] : D.wbase_##name)
+#define VMV_HSH(T, name) ((V == kEnvZOnly) ? 0u : D.wshift_##name)
     struct ListHdr
     {
         uint32_t n[5], off[5], wbase[5];  // indexed by PrimType; lists a variant does not compile in stay 0
@@ -1089,25 +1102,25 @@ namespace vmv
         if constexpr (MODE == 2)
         {
             lds_u32 *const mask = mask_src;
-            if constexpr ((V >> kSphere) & 1) list_masked<kSphere>(E, VMV_HN(kSphere, sphere), VMV_HOFF(kSphere, sphere), VMV_HWB(kSphere, sphere), x, y, z, r, rsq, ext, active, hit, mask);
-            if constexpr ((V >> kCapsule) & 1) list_masked<kCapsule>(E, VMV_HN(kCapsule, capsule), VMV_HOFF(kCapsule, capsule), VMV_HWB(kCapsule, capsule), x, y, z, r, rsq, ext, active, hit, mask);
-            if constexpr ((V >> kZCapsule) & 1) list_masked<kZCapsule>(E, VMV_HN(kZCapsule, zcapsule), VMV_HOFF(kZCapsule, zcapsule), VMV_HWB(kZCapsule, zcapsule), x, y, z, r, rsq, ext, active, hit, mask);
-            if constexpr ((V >> kCuboid) & 1) list_masked<kCuboid>(E, VMV_HN(kCuboid, cuboid), VMV_HOFF(kCuboid, cuboid), VMV_HWB(kCuboid, cuboid), x, y, z, r, rsq, ext, active, hit, mask);
-            if constexpr ((V >> kZCuboid) & 1) list_masked<kZCuboid>(E, VMV_HN(kZCuboid, zcuboid), VMV_HOFF(kZCuboid, zcuboid), VMV_HWB(kZCuboid, zcuboid), x, y, z, r, rsq, ext, active, hit, mask);
+            if constexpr ((V >> kSphere) & 1) list_masked<kSphere, V != kEnvZOnly>(E, VMV_HN(kSphere, sphere), VMV_HOFF(kSphere, sphere), VMV_HWB(kSphere, sphere), VMV_HSH(kSphere, sphere), x, y, z, r, rsq, ext, active, hit, mask);
+            if constexpr ((V >> kCapsule) & 1) list_masked<kCapsule, V != kEnvZOnly>(E, VMV_HN(kCapsule, capsule), VMV_HOFF(kCapsule, capsule), VMV_HWB(kCapsule, capsule), VMV_HSH(kCapsule, capsule), x, y, z, r, rsq, ext, active, hit, mask);
+            if constexpr ((V >> kZCapsule) & 1) list_masked<kZCapsule, V != kEnvZOnly>(E, VMV_HN(kZCapsule, zcapsule), VMV_HOFF(kZCapsule, zcapsule), VMV_HWB(kZCapsule, zcapsule), VMV_HSH(kZCapsule, zcapsule), x, y, z, r, rsq, ext, active, hit, mask);
+            if constexpr ((V >> kCuboid) & 1) list_masked<kCuboid, V != kEnvZOnly>(E, VMV_HN(kCuboid, cuboid), VMV_HOFF(kCuboid, cuboid), VMV_HWB(kCuboid, cuboid), VMV_HSH(kCuboid, cuboid), x, y, z, r, rsq, ext, active, hit, mask);
+            if constexpr ((V >> kZCuboid) & 1) list_masked<kZCuboid, V != kEnvZOnly>(E, VMV_HN(kZCuboid, zcuboid), VMV_HOFF(kZCuboid, zcuboid), VMV_HWB(kZCuboid, zcuboid), VMV_HSH(kZCuboid, zcuboid), x, y, z, r, rsq, ext, active, hit, mask);
         }
         else
         {
             constexpr bool MASK = (MODE == 1);
             const float ext_wave = wave_max_nonneg(active ? ext : 0.0f);
-            if constexpr ((V >> kSphere) & 1) list_full<G, kSphere, MASK>(E, VMV_HN(kSphere, sphere), VMV_HOFF(kSphere, sphere), D.off_md_sphere, VMV_HWB(kSphere, sphere), x, y, z, r, rsq, ext,
+            if constexpr ((V >> kSphere) & 1) list_full<G, kSphere, MASK>(E, VMV_HN(kSphere, sphere), VMV_HOFF(kSphere, sphere), D.off_md_sphere, VMV_HWB(kSphere, sphere), VMV_HSH(kSphere, sphere), x, y, z, r, rsq, ext,
                                         ext_wave, hit, mask_src);
-            if constexpr ((V >> kCapsule) & 1) list_full<G, kCapsule, MASK>(E, VMV_HN(kCapsule, capsule), VMV_HOFF(kCapsule, capsule), D.off_md_capsule, VMV_HWB(kCapsule, capsule), x, y, z, r, rsq,
+            if constexpr ((V >> kCapsule) & 1) list_full<G, kCapsule, MASK>(E, VMV_HN(kCapsule, capsule), VMV_HOFF(kCapsule, capsule), D.off_md_capsule, VMV_HWB(kCapsule, capsule), VMV_HSH(kCapsule, capsule), x, y, z, r, rsq,
                                          ext, ext_wave, hit, mask_src);
-            if constexpr ((V >> kZCapsule) & 1) list_full<G, kZCapsule, MASK>(E, VMV_HN(kZCapsule, zcapsule), VMV_HOFF(kZCapsule, zcapsule), D.off_md_zcapsule, VMV_HWB(kZCapsule, zcapsule), x, y, z, r,
+            if constexpr ((V >> kZCapsule) & 1) list_full<G, kZCapsule, MASK>(E, VMV_HN(kZCapsule, zcapsule), VMV_HOFF(kZCapsule, zcapsule), D.off_md_zcapsule, VMV_HWB(kZCapsule, zcapsule), VMV_HSH(kZCapsule, zcapsule), x, y, z, r,
                                           rsq, ext, ext_wave, hit, mask_src);
-            if constexpr ((V >> kCuboid) & 1) list_full<G, kCuboid, MASK>(E, VMV_HN(kCuboid, cuboid), VMV_HOFF(kCuboid, cuboid), D.off_md_cuboid, VMV_HWB(kCuboid, cuboid), x, y, z, r, rsq, ext,
+            if constexpr ((V >> kCuboid) & 1) list_full<G, kCuboid, MASK>(E, VMV_HN(kCuboid, cuboid), VMV_HOFF(kCuboid, cuboid), D.off_md_cuboid, VMV_HWB(kCuboid, cuboid), VMV_HSH(kCuboid, cuboid), x, y, z, r, rsq, ext,
                                         ext_wave, hit, mask_src);
-            if constexpr ((V >> kZCuboid) & 1) list_full<G, kZCuboid, MASK>(E, VMV_HN(kZCuboid, zcuboid), VMV_HOFF(kZCuboid, zcuboid), D.off_md_zcuboid, VMV_HWB(kZCuboid, zcuboid), x, y, z, r, rsq,
+            if constexpr ((V >> kZCuboid) & 1) list_full<G, kZCuboid, MASK>(E, VMV_HN(kZCuboid, zcuboid), VMV_HOFF(kZCuboid, zcuboid), D.off_md_zcuboid, VMV_HWB(kZCuboid, zcuboid), VMV_HSH(kZCuboid, zcuboid), x, y, z, r, rsq,
                                          ext, ext_wave, hit, mask_src);
         }
         hit = hit && active;
@@ -1184,10 +1197,10 @@ namespace vmv
     // One sorted list in the gate pass, driven by the broad-phase grid: this lane evaluates the reference's exact
     // predicates on the candidates of its own cell only, and records the fine-phase candidates (kCandidateMargin)
     // among them.  Lanes walk their own candidate bits; the loop runs until the busiest lane is done.
-    template <int T>
+    template <int T, bool SHARED>
     __device__ __forceinline__ void list_grid(const EnvView &E, const uint32_t n, const uint32_t off, const uint32_t wbase,
-                                              const uint32_t (&cw)[kMaskWords], float x, float y, float z, float r,
-                                              float rsq, float ext, bool &hit, lds_u32 *mask_lane)
+                                              const uint32_t shift, const uint32_t (&cw)[kMaskWords], float x, float y, float z,
+                                              float r, float rsq, float ext, bool &hit, lds_u32 *mask_lane)
     {
         if (n == 0) return;
         constexpr int REC = PrimTraits<T>::rec;
@@ -1197,6 +1210,7 @@ namespace vmv
             // (wave-uniform index into the preloaded words: selects, not a scratch array)
             const uint32_t k = wbase + w;
             uint32_t m = (k == 0u) ? cw[0] : (k == 1u) ? cw[1] : (k == 2u) ? cw[2] : cw[3];
+            if constexpr (SHARED) m = (m >> shift) & list_word_mask(n);  // (shared word: this list's bits)
             uint32_t fine = 0u;
             while (wave_any(m != 0u))  // branch-free body, see list_masked
             {
@@ -1210,7 +1224,10 @@ namespace vmv
                 const float tau = reach * (2.0f * kCandidateMargin) + kCandidateMargin * kCandidateMargin;
                 fine |= (live && v < tau) ? (1u << bit) : 0u;
             }
-            mask_lane[(wbase + w) * kWave] = (VMV_ABLATE_ENV == 4 || VMV_ABLATE_ENV == 5) ? 0u : fine;
+            if (VMV_ABLATE_ENV == 4 || VMV_ABLATE_ENV == 5) fine = 0u;
+            // (the first list of a word — shift 0 — stores, so the word needs no clearing; the lists that share it OR in)
+            if (shift == 0u) mask_lane[(wbase + w) * kWave] = fine;
+            else mask_lane[wbase * kWave] |= fine << shift;
         }
     }
 
@@ -1245,11 +1262,11 @@ namespace vmv
 #pragma unroll
         for (int w = 0; w < kMaskWords; ++w) cw[w] = (inside && (uint32_t) w < gw) ? cell[w] : 0u;
         if (VMV_ABLATE_ENV == 3) return inside && cw[0] == 0x12345u;  // measurement aid: gate overhead without the walks
-        if constexpr ((V >> kSphere) & 1) list_grid<kSphere>(E, VMV_HN(kSphere, sphere), VMV_HOFF(kSphere, sphere), VMV_HWB(kSphere, sphere), cw, x, y, z, r, rsq, ext, hit, mask_lane);
-        if constexpr ((V >> kCapsule) & 1) list_grid<kCapsule>(E, VMV_HN(kCapsule, capsule), VMV_HOFF(kCapsule, capsule), VMV_HWB(kCapsule, capsule), cw, x, y, z, r, rsq, ext, hit, mask_lane);
-        if constexpr ((V >> kZCapsule) & 1) list_grid<kZCapsule>(E, VMV_HN(kZCapsule, zcapsule), VMV_HOFF(kZCapsule, zcapsule), VMV_HWB(kZCapsule, zcapsule), cw, x, y, z, r, rsq, ext, hit, mask_lane);
-        if constexpr ((V >> kCuboid) & 1) list_grid<kCuboid>(E, VMV_HN(kCuboid, cuboid), VMV_HOFF(kCuboid, cuboid), VMV_HWB(kCuboid, cuboid), cw, x, y, z, r, rsq, ext, hit, mask_lane);
-        if constexpr ((V >> kZCuboid) & 1) list_grid<kZCuboid>(E, VMV_HN(kZCuboid, zcuboid), VMV_HOFF(kZCuboid, zcuboid), VMV_HWB(kZCuboid, zcuboid), cw, x, y, z, r, rsq, ext, hit, mask_lane);
+        if constexpr ((V >> kSphere) & 1) list_grid<kSphere, V != kEnvZOnly>(E, VMV_HN(kSphere, sphere), VMV_HOFF(kSphere, sphere), VMV_HWB(kSphere, sphere), VMV_HSH(kSphere, sphere), cw, x, y, z, r, rsq, ext, hit, mask_lane);
+        if constexpr ((V >> kCapsule) & 1) list_grid<kCapsule, V != kEnvZOnly>(E, VMV_HN(kCapsule, capsule), VMV_HOFF(kCapsule, capsule), VMV_HWB(kCapsule, capsule), VMV_HSH(kCapsule, capsule), cw, x, y, z, r, rsq, ext, hit, mask_lane);
+        if constexpr ((V >> kZCapsule) & 1) list_grid<kZCapsule, V != kEnvZOnly>(E, VMV_HN(kZCapsule, zcapsule), VMV_HOFF(kZCapsule, zcapsule), VMV_HWB(kZCapsule, zcapsule), VMV_HSH(kZCapsule, zcapsule), cw, x, y, z, r, rsq, ext, hit, mask_lane);
+        if constexpr ((V >> kCuboid) & 1) list_grid<kCuboid, V != kEnvZOnly>(E, VMV_HN(kCuboid, cuboid), VMV_HOFF(kCuboid, cuboid), VMV_HWB(kCuboid, cuboid), VMV_HSH(kCuboid, cuboid), cw, x, y, z, r, rsq, ext, hit, mask_lane);
+        if constexpr ((V >> kZCuboid) & 1) list_grid<kZCuboid, V != kEnvZOnly>(E, VMV_HN(kZCuboid, zcuboid), VMV_HOFF(kZCuboid, zcuboid), VMV_HWB(kZCuboid, zcuboid), VMV_HSH(kZCuboid, zcuboid), cw, x, y, z, r, rsq, ext, hit, mask_lane);
         hit = hit && active;
         if constexpr (((V >> 5) & 1) == 0) return hit;
         for (uint32_t hi = 0; hi < D.n_heightfield; ++hi)  // validity.hh:131-137
@@ -1441,6 +1458,7 @@ namespace vmv
 #undef VMV_HN
 #undef VMV_HOFF
 #undef VMV_HWB
+#undef VMV_HSH
     __device__ __forceinline__ bool env_flag(lds_ptr scratch)
     {
         return ((lds_u32 *) scratch)[kWave + __lane_id()] != 0u;

@@ -45,6 +45,30 @@ def shell_spec(seed=0, n_spheres=32, n_cuboids=32, rmin=0.45, rmax=0.95):
     return spec
 
 
+def mixed_spec(seed=0, rmin=0.45, rmax=0.95):
+    """64 primitives of every kind the sorted lists hold — 16 spheres + 16 z-aligned cuboids (shell_spec), 16 rotated
+    cuboids, 8 capsules, 8 z-aligned capsules — what MotionBenchMaker-style scenes look like to the kernels (the
+    five-list variant), next to BASELINE config 2's spheres and z-aligned cuboids.  Diagnostics workload, not a BASELINE one."""
+    rng = np.random.default_rng(seed + 101)
+    spec = shell_spec(seed, 16, 16, rmin, rmax)
+
+    def pos(zmax=1.3):
+        ang, rad = rng.uniform(0, 2 * np.pi), rng.uniform(rmin, rmax)
+        return np.array([rad * np.cos(ang), rad * np.sin(ang), rng.uniform(0.0, zmax)], np.float32)
+
+    for _ in range(16):
+        spec.append(("cuboid", rot_cuboid(pos(), rng.uniform(-1, 1, 3), rng.uniform(0.03, 0.12, 3))))
+    for _ in range(8):
+        p1 = pos()
+        spec.append(("capsule", capsule(p1, (p1 + rng.uniform(-0.3, 0.3, 3)).astype(np.float32), rng.uniform(0.02, 0.08))))
+    for _ in range(8):
+        p1 = pos(1.0)
+        p2 = p1.copy()
+        p2[2] += np.float32(rng.uniform(0.1, 0.5))
+        spec.append(("capsule", capsule(p1, p2, rng.uniform(0.02, 0.08))))
+    return spec
+
+
 def shell_cloud(n, seed=0, rmin=0.6, rmax=1.2, zmin=0.2, zmax=1.5):
     rng = np.random.default_rng(seed)
     ang = rng.uniform(0, 2 * np.pi, n)
