@@ -124,6 +124,13 @@ def main():
                                                         "baxter": (0.9, 1.6)}[robot]))
             a, b = uniform(mod, n, 1), None
             shape = "uniform configurations vs 16 spheres, 16 z-cuboids, 16 rotated cuboids, 8 capsules, 8 z-capsules"
+        elif cfg.startswith("prm_"):  # diagnostics: config 4's workload for any robot (2^18 roadmap-shaped edges)
+            robot = cfg.split("_", 1)[1]
+            mod, n, unit = getattr(vamp, robot), int((1 << 18) * args.scale), "edges/s"
+            env = environment_from_spec(shell_spec(0, 32, 32, *{"panda": (0.45, 0.95), "ur5": (0.45, 0.95), "fetch": (0.6, 1.2),
+                                                              "baxter": (0.9, 1.6)}[robot]))
+            a, b = prm_shaped_edges(mod, env, n, 0.2, 1.5, seed=3)
+            shape = "PRM-shaped: valid Halton samples x valid neighbours at U[0.2,1.5] rad, 64 primitives"
         elif cfg == "config3":
             mod, n, unit = vamp.fetch, int((1 << 20) * args.scale), "checks/s"
             env = environment_from_spec([("capt", (shell_cloud(10000, 3), *RADII["fetch"], POINT_RADIUS))])

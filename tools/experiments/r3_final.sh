@@ -13,3 +13,8 @@ for l in open('gpurun_out/r3y_configs.jsonl'):
     d=json.loads(l); print(d['config'], d['robot'], round(d['ms'],4), '%.3e'%d['value'], d['unit'], round(d['valid_fraction'],3))"
 timeout -k 10 200 python tools/bench_robots.py > gpurun_out/r3y_robots.jsonl 2>/dev/null; cut -c1-140 gpurun_out/r3y_robots.jsonl
 timeout -k 10 400 python tools/fuzz_gpu.py --minutes 5 --seed 33 > gpurun_out/r3y_fuzz.log 2>&1; echo "fuzz rc=$?"; tail -1 gpurun_out/r3y_fuzz.log
+timeout -k 10 300 python tools/bench_configs.py prm_panda prm_fetch prm_baxter > gpurun_out/r3y_prm_robots.jsonl 2>/dev/null; echo "prm rc=$?"; python3 -c "
+import json
+for l in open('gpurun_out/r3y_prm_robots.jsonl'):
+    if l.startswith('{'):
+        d=json.loads(l); print(d['config'], d['robot'], round(d['ms'],4), '%.3e'%d['value'], d['unit'], round(d['valid_fraction'],3))"

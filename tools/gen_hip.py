@@ -325,7 +325,7 @@ ENV_BLOCKS = {"panda": 6, "ur5": 5, "baxter": 5}  # (baxter: 0.331 -> 0.307 ms p
 # workgroups per CU the self kernel is compiled for (512 / blocks VGPRs per lane) and fine spheres per slab chunk of the
 # self-collision kernels.  Panda, measured (blocks x chunk, self kernel ms per 1M configs): 3x8 0.145, 4x8 0.133,
 # 4x7 0.127, 4x6 0.126, 4x5 0.132, 4x4 0.140, 5x5 0.210 - with chunks of 8 the fourth workgroup did not fit the LDS.
-SELF_BLOCKS = {"panda": 4, "ur5": 3, "baxter": 3}  # (baxter: 0.289 -> 0.227 ms at 3; fetch is faster at 2 than at 3)
+SELF_BLOCKS = {"panda": 4, "ur5": 4, "baxter": 3}  # (baxter: 0.289 -> 0.227 ms at 3; fetch is faster at 2 than at 3)
 SELF_CHUNK = {"panda": 6}
 FUSED_BLOCKS = {"panda": int(os.environ.get("VMV_FUSED_BLOCKS", 4))}
 for _r in ("panda", "ur5", "fetch", "baxter"):  # tuning knobs: VMV_{SELF,ENV}_BLOCKS_<ROBOT>, VMV_{SELF,ENV}_CHUNK_<ROBOT>

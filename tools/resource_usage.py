@@ -41,4 +41,4 @@ if __name__ == "__main__":
             for k in rows:
                 print(f"  {k['name']:34s} vgpr {k.get('VGPRs'):>4s} agpr {k.get('AGPRs'):>3s} sspill {k.get('SGPRs Spill'):>4s} "
                       f"vspill {k.get('VGPRs Spill'):>3s} scratch {k.get('ScratchSize [bytes/lane]'):>4s} "
-                      f"occ {k.get('Occupancy [waves/SIMD]')}")
+                      f"lds {k.get('LDS Size [bytes/block]'):>6s} occ {k.get('Occupancy [waves/SIMD]')}")
