@@ -16,14 +16,14 @@ from vamp_mvt_amd.workloads import environment_from_spec, prm_shaped_edges, shel
 
 vamp.set_device(0)
 env = environment_from_spec(shell_spec(0))
-mod = vamp.ur5
+mod = getattr(vamp, os.environ.get("SMALL_ROBOT", "ur5"))  # (SMALL_ROBOT=panda: the other robot with a fused task kernel)
 lo = torch.from_numpy(mod.lower_bounds()).cuda()
 hi = torch.from_numpy(mod.upper_bounds()).cuda()
 g = torch.Generator(device="cuda").manual_seed(3)
-N = 1 << 20
+N = int(os.environ.get("SMALL_N", 1 << 20))
 pa, pb = prm_shaped_edges(mod, env, N, 0.2, 1.5, seed=3)
-ua = (lo + (hi - lo) * torch.rand((N, 6), generator=g, device="cuda")).contiguous()
-d = torch.randn((N, 6), generator=g, device="cuda")
+ua = (lo + (hi - lo) * torch.rand((N, len(lo)), generator=g, device="cuda")).contiguous()
+d = torch.randn((N, len(lo)), generator=g, device="cuda")
 ub = (ua + d / d.norm(dim=1, keepdim=True) * (0.2 + 1.3 * torch.rand((N, 1), generator=g, device="cuda"))).contiguous()
 sizes = [int(x) for x in sys.argv[1:]] or [256, 2048, 16384, 131072, 262144, 524288, N]
 modes = os.environ.get("EDGE_MODES", "default").split(",")  # VMV_EDGE_TASKS values to compare (default = by batch size)

@@ -327,7 +327,10 @@ ENV_BLOCKS = {"panda": 6, "ur5": 5, "baxter": 5}  # (baxter: 0.331 -> 0.307 ms p
 # 4x7 0.127, 4x6 0.126, 4x5 0.132, 4x4 0.140, 5x5 0.210 - with chunks of 8 the fourth workgroup did not fit the LDS.
 SELF_BLOCKS = {"panda": 4, "ur5": 4, "baxter": 3}  # (baxter: 0.289 -> 0.227 ms at 3; fetch is faster at 2 than at 3)
 SELF_CHUNK = {"panda": 6}
-FUSED_BLOCKS = {"panda": int(os.environ.get("VMV_FUSED_BLOCKS", 4))}
+# fused one-FK kernels (the task kernel of planner-sized edge batches, n < 16,384): at 3 workgroups per CU (168 VGPRs) Panda's
+# body spills 28 VGPRs instead of 77 at 4, and such batches never fill more than 2 - 3 waves per SIMD: 256 edges 0.104 ->
+# 0.096 ms, 2,048 0.133 -> 0.126, 8,192 0.148 -> 0.135 (at 2: 0.094 / 0.123 / 0.148); UR5 (no spill at 3) unchanged
+FUSED_BLOCKS = {r: int(os.environ.get("VMV_FUSED_BLOCKS", 3)) for r in ("panda", "ur5")}
 for _r in ("panda", "ur5", "fetch", "baxter"):  # tuning knobs: VMV_{SELF,ENV}_BLOCKS_<ROBOT>, VMV_{SELF,ENV}_CHUNK_<ROBOT>
     if f"VMV_ENV_BLOCKS_{_r.upper()}" in os.environ:
         ENV_BLOCKS[_r] = int(os.environ[f"VMV_ENV_BLOCKS_{_r.upper()}"])
