@@ -326,7 +326,11 @@ ENV_BLOCKS = {"panda": 6, "ur5": 5, "baxter": 5}  # (baxter: 0.331 -> 0.307 ms p
 # self-collision kernels.  Panda, measured (blocks x chunk, self kernel ms per 1M configs): 3x8 0.145, 4x8 0.133,
 # 4x7 0.127, 4x6 0.126, 4x5 0.132, 4x4 0.140, 5x5 0.210 - with chunks of 8 the fourth workgroup did not fit the LDS.
 SELF_BLOCKS = {"panda": 4, "ur5": 4, "baxter": 3}  # (baxter: 0.289 -> 0.227 ms at 3; fetch is faster at 2 than at 3)
-SELF_CHUNK = {"panda": 6}
+SELF_CHUNK = {"panda": 6, "ur5": 5}
+# the (edge, rake) task kernel of the self-collision half: the configuration kernel's bound unless listed.  UR5 with chunks of
+# 5 fits five workgroups per CU (96 VGPRs, 13 spilled, 30.4 KB of LDS): BASELINE config 4 5.46 -> 5.20 ms; its configuration
+# kernel is 1.5 % slower that way and stays at four
+MOTION_SELF_BLOCKS = {"ur5": 5}
 # fused one-FK kernels (the task kernel of planner-sized edge batches, n < 16,384): at 3 workgroups per CU (168 VGPRs) Panda's
 # body spills 28 VGPRs instead of 77 at 4, and such batches never fill more than 2 - 3 waves per SIMD: 256 edges 0.104 ->
 # 0.096 ms, 2,048 0.133 -> 0.126, 8,192 0.148 -> 0.135 (at 2: 0.094 / 0.123 / 0.148); UR5 (no spill at 3) unchanged
@@ -340,6 +344,8 @@ for _r in ("panda", "ur5", "fetch", "baxter"):  # tuning knobs: VMV_{SELF,ENV}_B
         SELF_BLOCKS[_r] = int(os.environ[f"VMV_SELF_BLOCKS_{_r.upper()}"])
     if f"VMV_SELF_CHUNK_{_r.upper()}" in os.environ:
         SELF_CHUNK[_r] = int(os.environ[f"VMV_SELF_CHUNK_{_r.upper()}"])
+    if f"VMV_MOTION_SELF_BLOCKS_{_r.upper()}" in os.environ:
+        MOTION_SELF_BLOCKS[_r] = int(os.environ[f"VMV_MOTION_SELF_BLOCKS_{_r.upper()}"])
 SELF_DENSE_RATE = float(os.environ.get('VMV_SELF_DENSE_RATE', 0.5))   # groups whose bounding-pair gate fires for at least this share of uniform configurations ...
 SELF_DENSE_MIN_A = 3    # ... and whose A side is at least this large use the pre-test + compaction form
 SPARSE_BATCH = 8        # sparse groups merged per item list (the list holds SPARSE_BATCH * 64 entries = CHUNK * 64)
@@ -1128,6 +1134,7 @@ def emit_robot(m):
     L.append(f"        return {n}::static_env_hit(E);")
     L.append("    }")
     L.append(f"    static constexpr int kSelfBlocks = {SELF_BLOCKS.get(n, 2)};  // workgroups per CU the self-collision kernel is compiled for")
+    L.append(f"    static constexpr int kMotionSelfBlocks = {MOTION_SELF_BLOCKS.get(n, SELF_BLOCKS.get(n, 2))};  // ... and its (edge, rake) task kernel")
     L.append("    template <int G, int V>")
     L.append("    static __device__ __forceinline__ bool")
     L.append("    fkcc_env(const vmv::EnvView &E, const float (&q)[kDim], vmv::lds_ptr slab, const bool skip)")
