@@ -325,7 +325,9 @@ ENV_BLOCKS = {"panda": 6, "ur5": 5, "baxter": 5}  # (baxter: 0.331 -> 0.307 ms p
 # workgroups per CU the self kernel is compiled for (512 / blocks VGPRs per lane) and fine spheres per slab chunk of the
 # self-collision kernels.  Panda, measured (blocks x chunk, self kernel ms per 1M configs): 3x8 0.145, 4x8 0.133,
 # 4x7 0.127, 4x6 0.126, 4x5 0.132, 4x4 0.140, 5x5 0.210 - with chunks of 8 the fourth workgroup did not fit the LDS.
-SELF_BLOCKS = {"panda": 4, "ur5": 4, "baxter": 3}  # (baxter: 0.289 -> 0.227 ms at 3; fetch is faster at 2 than at 3)
+# (baxter: 0.289 -> 0.227 ms at 3.  Fetch was faster at 2 than at 3 while its 41.3 KB of LDS allowed three workgroups; without
+# the attachment radii (40.2 KB) four fit: 128 VGPRs, 11 - 13 spilled: config 3 0.581 -> 0.569 ms, its edges 1.617 -> 1.538)
+SELF_BLOCKS = {"panda": 4, "ur5": 4, "fetch": 4, "baxter": 3}
 SELF_CHUNK = {"panda": 6, "ur5": 5}
 # the (edge, rake) task kernel of the self-collision half: the configuration kernel's bound unless listed.  UR5 with chunks of
 # 5 fits five workgroups per CU (96 VGPRs, 13 spilled, 30.4 KB of LDS): BASELINE config 4 5.46 -> 5.20 ms; its configuration
